@@ -1,0 +1,84 @@
+"""CPU: pin oracle/bt_oracle.py to the golden vectors produced by running the reference
+(tools/make_goldens.py).  Runs without a GPU."""
+import pytest
+import torch
+
+from conftest import assert_close, golden_names, layer_tensors, load_golden
+from oracle import bt_oracle as O
+from bayesian_torch_amd.harness import resnet as H
+
+LAYER_FIX = golden_names("linear_") + golden_names("conv2d_")
+
+
+@pytest.mark.parametrize("name", LAYER_FIX)
+def test_layer_forward_and_kl(name):
+    g = layer_tensors(load_golden(name))
+    if "flipout" in name:
+        out = O.flipout_fwd_ref(g["x"], g["mu_w"], g["rho_w"], g["eps_w"], g["sign_in"], g["sign_out"],
+                                g["mu_b"], g["rho_b"], g["eps_b"], g["conv"])
+    else:
+        out = O.reparam_fwd_ref(g["x"], g["mu_w"], g["rho_w"], g["eps_w"], g["mu_b"], g["rho_b"], g["eps_b"], g["conv"])
+    # same ATen ops on the same kind of host: expected bit-equal; tolerance covers other CPUs
+    assert_close(out, g["out"], rtol=1e-5, atol_scale=1e-6, what=name + ".out")
+    kl = O.kl_layer_ref(g["mu_w"], g["rho_w"], g["prior_mu_w"], g["prior_sigma_w"],
+                        g["mu_b"], g["rho_b"], g["prior_mu_b"], g["prior_sigma_b"])
+    assert_close(kl, g["kl"], rtol=1e-6, atol_scale=0, what=name + ".kl")
+    assert_close(O.kl_normal_ref(g["mu_w"], O.softplus_ref(g["rho_w"]), g["prior_mu_w"], g["prior_sigma_w"]),
+                 g["kl_w"], rtol=1e-6, atol_scale=0, what=name + ".kl_w")
+
+
+def _build(meta):
+    torch.manual_seed(meta["seed"])
+    if len(meta["x_shape"]) == 2:
+        net = H.mlp((3072, 512, 10))
+    else:
+        net = H.resnet18(10, width=8 if "w8" in meta["_name"] else 64)
+    O.ref_dnn_to_bnn(net, meta["btype"])
+    H.fill_bayes_params(net, meta["seed"])
+    return net.eval()
+
+
+@pytest.mark.parametrize("name", ["model_r18w8_reparam", "model_r18w8_flipout", "model_mlp_reparam"])
+def test_model_replay_from_seed(name):
+    """The oracle modules consume the global CPU generator in the reference's draw order,
+    so re-seeding reproduces the reference's logits sample by sample."""
+    g = load_golden(name)
+    meta = dict(g["meta"], _name=name)
+    net = _build(meta)
+    # parameter recipe produced the same numbers as in the generator
+    chk = [[float(p.double().sum()), float((p.double() ** 2).sum())] for _, m in H.bayes_layers(net) for p in m.parameters()]  # noqa
+    assert torch.allclose(torch.tensor(chk), torch.tensor(meta["param_checksums"]), rtol=1e-12, atol=0)
+    gen = torch.Generator().manual_seed(meta["seed"] + 7)
+    x = torch.randn(*meta["x_shape"], generator=gen)
+    if "x" in g:
+        assert torch.equal(x, g["x"])
+    with torch.no_grad():
+        for s in range(meta["S"]):
+            torch.manual_seed(meta["seed"] * 100 + s)
+            logits = net(x)
+            assert_close(logits, g["logits"][s], rtol=1e-4, atol_scale=1e-5, what=f"{name}.logits[{s}]")
+        assert_close(O.ref_get_kl_loss(net), g["kl"], rtol=1e-6, atol_scale=0, what=name + ".kl")
+    p_sum, ent_sum, l_sum = O.mc_epilogue_ref(g["logits"])
+    assert_close(p_sum / meta["S"], g["mean_prob"], rtol=1e-5, atol_scale=1e-6, what=name + ".mean_prob")
+
+
+@pytest.mark.parametrize("name", ["model_r18_reparam", "model_r18_flipout"])
+def test_full_width_r18_replay(name):
+    """cfg3 / cfg4 of BASELINE.json at full width: only (seed, logits, kl, checksums) are stored."""
+    g = load_golden(name)
+    meta = dict(g["meta"], _name=name)
+    torch.set_num_threads(8)
+    net = _build(meta)
+    gen = torch.Generator().manual_seed(meta["seed"] + 7)
+    x = torch.randn(*meta["x_shape"], generator=gen)
+    with torch.no_grad():
+        torch.manual_seed(meta["seed"] * 100)
+        logits = net(x)
+        assert_close(logits, g["logits"][0], rtol=1e-4, atol_scale=1e-5, what=name + ".logits")
+        assert_close(O.ref_get_kl_loss(net), g["kl"], rtol=1e-6, atol_scale=0, what=name + ".kl")
+
+
+def test_get_rho():
+    g = load_golden("get_rho")
+    assert_close(O.get_rho_ref(g["w"], 0.1), g["rho_0p1"], rtol=1e-6, atol_scale=0)
+    assert_close(O.get_rho_ref(g["w"], 0.5), g["rho_0p5"], rtol=1e-6, atol_scale=0)
