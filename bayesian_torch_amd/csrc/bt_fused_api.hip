@@ -1,0 +1,100 @@
+// C-ABI entry points of the four fused forwards: argument validation, geometry, launch.
+#include <string.h>
+
+#include "bt_fused_fwd.h"
+
+namespace bt {
+int launch_reparam(bool linear, FwdArgs& a, hipStream_t stream);
+int launch_flipout(bool linear, FwdArgs& a, hipStream_t stream);
+
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const float* x, int64_t x_sample_stride, const bt_params* p,
+               const bt_draws* d, float* out, float* kl_out, void* ws, size_t ws_bytes, bt_stream_t stream, const char* who) {
+  char msg[256];
+  auto bad = [&](const char* what) {
+    snprintf(msg, sizeof(msg), "%s: %s", who, what);
+    return set_error(BT_ERR_BAD_ARG, msg);
+  };
+  if (!x || !p || !d || !out) return bad("null argument");
+  if (!p->mu_w || !p->rho_w) return bad("mu_w / rho_w are required");
+  if ((p->mu_b == nullptr) != (p->rho_b == nullptr)) return bad("mu_b and rho_b must both be given or both be NULL");
+  if (S <= 0) return bad("S must be >= 1");
+  if (g.B <= 0 || g.Ci <= 0 || g.H <= 0 || g.W <= 0 || g.Co <= 0 || g.kh <= 0 || g.kw <= 0) return bad("non-positive dimension");
+  if (g.sh <= 0 || g.sw <= 0 || g.dh <= 0 || g.dw <= 0 || g.ph < 0 || g.pw < 0 || g.groups <= 0) return bad("bad stride / padding / dilation / groups");
+  if (g.Ci % g.groups || g.Co % g.groups) return bad("invalid in_channels size");  // conv_variational.py:270-273
+  if (x_sample_stride < 0) return bad("negative x_sample_stride");
+  if (kl_out) {
+    if (!p->prior_mu_w || !p->prior_sigma_w) return bad("kl_out given but weight priors are NULL");
+    if (p->mu_b && (!p->prior_mu_b || !p->prior_sigma_b)) return bad("kl_out given but bias priors are NULL");
+    if (!ws || ws_bytes < BT_WORKSPACE_BYTES) {
+      snprintf(msg, sizeof(msg), "%s: workspace smaller than BT_WORKSPACE_BYTES", who);
+      return set_error(BT_ERR_WORKSPACE, msg);
+    }
+  }
+  if (p->mu_b == nullptr && d->eps_b) return bad("eps_b given for a layer without bias");
+  if (!flip && (d->sign_in || d->sign_out)) return bad("sign tensors are Flipout-only");
+
+  const int Ho = (g.H + 2 * g.ph - g.dh * (g.kh - 1) - 1) / g.sh + 1;
+  const int Wo = (g.W + 2 * g.pw - g.dw * (g.kw - 1) - 1) / g.sw + 1;
+  if (Ho <= 0 || Wo <= 0) return bad("empty output");
+
+  FwdArgs a;
+  FwdArgs zero = {}; a = zero;
+  a.x = x, a.mu_w = p->mu_w, a.rho_w = p->rho_w, a.mu_b = p->mu_b, a.rho_b = p->rho_b;
+  a.pmu_w = p->prior_mu_w, a.psig_w = p->prior_sigma_w, a.pmu_b = p->prior_mu_b, a.psig_b = p->prior_sigma_b;
+  a.eps_w = d->eps_w, a.eps_b = d->eps_b, a.sign_in = d->sign_in, a.sign_out = d->sign_out;
+  a.out = out, a.kl_out = kl_out;
+  a.slots = kl_out ? ws_slots(ws) : nullptr;
+  a.counter = kl_out ? ws_counter(ws) : nullptr;
+  a.B = g.B, a.Ci = g.Ci, a.H = g.H, a.W = g.W, a.Co = g.Co, a.KH = g.kh, a.KW = g.kw;
+  a.SH = g.sh, a.SW = g.sw, a.PH = g.ph, a.PW = g.pw, a.DH = g.dh, a.DW = g.dw, a.G = g.groups;
+  a.Ho = Ho, a.Wo = Wo, a.HoWo = Ho * Wo;
+  const long long M = (long long)g.B * Ho * Wo;
+  a.Cig = g.Ci / g.groups, a.Cog = g.Co / g.groups;
+  const long long K = (long long)a.Cig * g.kh * g.kw;
+  a.x_elems = (long long)g.B * g.Ci * g.H * g.W;
+  a.out_elems = M * g.Co;
+  a.w_elems = (long long)g.Co * K;
+  // 32-bit index budget of the kernel (tile indices, hashed sign indices, Philox block index)
+  if (M > 0x7FFFFFFFll || K > 0x7FFFFFFFll || a.x_elems > 0xFFFFFFFFll || a.out_elems > 0xFFFFFFFFll || a.w_elems > (1ll << 34))
+    return set_error(BT_ERR_UNSUPPORTED, "fused forward: tensor too large for 32-bit tile indexing");
+  a.M = (int)M, a.K = (int)K, a.S = S;
+  a.x_sample_stride = x_sample_stride;
+  a.w_vec = ((K & 3) == 0) && al16(p->mu_w) && al16(p->rho_w) && (!d->eps_w || al16(d->eps_w)) &&
+            (!kl_out || (al16(p->prior_mu_w) && al16(p->prior_sigma_w)));
+  a.x_vec = linear && ((K & 3) == 0) && al16(x) && ((x_sample_stride & 3) == 0) && (!d->sign_in || al16(d->sign_in));
+  a.do_kl = kl_out != nullptr;
+  a.seed_lo = (uint32_t)d->rng.seed, a.seed_hi = (uint32_t)(d->rng.seed >> 32);
+  a.call = d->rng.call, a.call_base = d->rng.call_base_dev, a.layer_id = d->rng.layer_id, a.sample0 = d->rng.sample0;
+  return flip ? launch_flipout(linear, a, (hipStream_t)stream) : launch_reparam(linear, a, (hipStream_t)stream);
+}
+
+static bt_conv2d_geom linear_geom(int B, int In, int Out) {
+  bt_conv2d_geom g;
+  g.B = B, g.Ci = In, g.H = 1, g.W = 1, g.Co = Out, g.kh = 1, g.kw = 1;
+  g.sh = g.sw = 1, g.ph = g.pw = 0, g.dh = g.dw = 1, g.groups = 1;
+  return g;
+}
+}  // namespace bt
+
+extern "C" int bt_reparam_linear_fwd(int32_t B, int32_t In, int32_t Out, int32_t S, const float* x, int64_t x_sample_stride,
+                                     const bt_params* p, const bt_draws* d, float* out, float* kl_out, void* ws, size_t ws_bytes,
+                                     bt_stream_t stream) {
+  return bt::run(false, true, bt::linear_geom(B, In, Out), S, x, x_sample_stride, p, d, out, kl_out, ws, ws_bytes, stream, "bt_reparam_linear_fwd");
+}
+extern "C" int bt_flipout_linear_fwd(int32_t B, int32_t In, int32_t Out, int32_t S, const float* x, int64_t x_sample_stride,
+                                     const bt_params* p, const bt_draws* d, float* out, float* kl_out, void* ws, size_t ws_bytes,
+                                     bt_stream_t stream) {
+  return bt::run(true, true, bt::linear_geom(B, In, Out), S, x, x_sample_stride, p, d, out, kl_out, ws, ws_bytes, stream, "bt_flipout_linear_fwd");
+}
+extern "C" int bt_reparam_conv2d_fwd(const bt_conv2d_geom* g, int32_t S, const float* x, int64_t x_sample_stride, const bt_params* p,
+                                     const bt_draws* d, float* out, float* kl_out, void* ws, size_t ws_bytes, bt_stream_t stream) {
+  if (!g) return bt::set_error(BT_ERR_BAD_ARG, "bt_reparam_conv2d_fwd: null geometry");
+  return bt::run(false, false, *g, S, x, x_sample_stride, p, d, out, kl_out, ws, ws_bytes, stream, "bt_reparam_conv2d_fwd");
+}
+extern "C" int bt_flipout_conv2d_fwd(const bt_conv2d_geom* g, int32_t S, const float* x, int64_t x_sample_stride, const bt_params* p,
+                                     const bt_draws* d, float* out, float* kl_out, void* ws, size_t ws_bytes, bt_stream_t stream) {
+  if (!g) return bt::set_error(BT_ERR_BAD_ARG, "bt_flipout_conv2d_fwd: null geometry");
+  return bt::run(true, false, *g, S, x, x_sample_stride, p, d, out, kl_out, ws, ws_bytes, stream, "bt_flipout_conv2d_fwd");
+}

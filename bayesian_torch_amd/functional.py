@@ -1,0 +1,91 @@
+"""Functional form of the four fused forwards: tensors in, one C-ABI call, tensors out.
+The layer modules (layers/_fused.py) are thin wrappers over ``fused_forward``."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, dh, dw):
+    return (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1, (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+
+
+def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=None, S=1, shared_x=True,
+                  priors=None, eps_w=None, eps_b=None, sign_in=None, sign_out=None,
+                  seed=0, call=0, layer_id=0, sample0=0, call_base=None, want_kl=False, workspace_owner="functional"):
+    """x: [B, In] (conv=None) or [B, Ci, H, W]; when ``shared_x`` is False x holds S stacked batches
+    ([S*B, ...]).  conv: dict(stride=(sh,sw), padding=(ph,pw), dilation=(dh,dw), groups=g) for Conv2d.
+    priors: (prior_mu_w, prior_sigma_w, prior_mu_b, prior_sigma_b) -- required when want_kl.
+    eps_*/sign_*: injected draws with a leading S axis, or None for the on-chip generators.
+    Returns (out [S*B, ...], kl or None)."""
+    x = _lib.dev_f32(x, "input")
+    dev = x.device
+    tens = dict(mu_w=mu_w, rho_w=rho_w, mu_b=mu_b, rho_b=rho_b, eps_w=eps_w, eps_b=eps_b, sign_in=sign_in, sign_out=sign_out)
+    for k, t in tens.items():
+        t = _lib.dev_f32(t, k)
+        if t is not None and t.device != dev:
+            raise RuntimeError(f"{k} on {t.device} but input on {dev}")
+        tens[k] = t
+    if x.shape[0] % (1 if shared_x else S):
+        raise RuntimeError("stacked input rows are not a multiple of S")
+    B = x.shape[0] // (1 if shared_x else S)
+    Co = mu_w.shape[0]
+    if conv is None:
+        In = mu_w.shape[1]
+        if x.dim() != 2 or x.shape[1] != In:
+            raise RuntimeError(f"expected [N, {In}] input, got {tuple(x.shape)}")
+        tail = (Co,)
+    else:
+        kh, kw = mu_w.shape[2], mu_w.shape[3]
+        (sh, sw), (ph, pw), (dh, dw), groups = conv["stride"], conv["padding"], conv["dilation"], conv["groups"]
+        Ci, H, W = x.shape[1], x.shape[2], x.shape[3]
+        if Ci != mu_w.shape[1] * groups:
+            raise RuntimeError(f"input has {Ci} channels, weight expects {mu_w.shape[1] * groups}")
+        Ho, Wo = conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, dh, dw)
+        if Ho <= 0 or Wo <= 0:
+            raise RuntimeError("convolution output would be empty")
+        tail = (Co, Ho, Wo)
+        geom = _lib.bt_conv2d_geom(B, Ci, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups)
+    x_elems = x.numel() // (1 if shared_x else S)
+    out = torch.empty((S * B,) + tail, dtype=torch.float32, device=dev)
+    kl = ws = None
+    pr = [None] * 4
+    if want_kl:
+        if priors is None:
+            raise ValueError("want_kl needs priors")
+        pr = [_lib.dev_f32(t, "prior") for t in priors]
+        kl = torch.empty((), dtype=torch.float32, device=dev)
+        ws = _lib.workspace(workspace_owner, dev)
+    P = _lib.bt_params(tens["mu_w"].data_ptr(), tens["rho_w"].data_ptr(), _lib.ptr(tens["mu_b"]), _lib.ptr(tens["rho_b"]),
+                       _lib.ptr(pr[0]), _lib.ptr(pr[1]), _lib.ptr(pr[2]), _lib.ptr(pr[3]))
+    R = _lib.bt_rng(int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(call_base), int(call) & 0xFFFFFFFF, int(layer_id), int(sample0), 0)
+    D = _lib.bt_draws(_lib.ptr(tens["eps_w"]), _lib.ptr(tens["eps_b"]), _lib.ptr(tens["sign_in"]), _lib.ptr(tens["sign_out"]), R)
+    tail_args = (x.data_ptr(), 0 if shared_x else x_elems, C.byref(P), C.byref(D), out.data_ptr(), _lib.ptr(kl), _lib.ptr(ws),
+                 _lib.WORKSPACE_BYTES if want_kl else 0, _lib.stream_ptr())
+    L = _lib.lib()
+    if conv is None:
+        fn = L.bt_flipout_linear_fwd if flip else L.bt_reparam_linear_fwd
+        _lib.check(fn(B, In, Co, S, *tail_args))
+    else:
+        fn = L.bt_flipout_conv2d_fwd if flip else L.bt_reparam_conv2d_fwd
+        _lib.check(fn(C.byref(geom), S, *tail_args))
+    return out, kl
+
+
+def rng_fill(kind, seed, call, layer_id, sample0, tensor_id, S, n, device, call_base=None):
+    """Materialise the on-chip stream: kind 'normal' (eps) or 'sign'. -> [S, n]"""
+    R = _lib.bt_rng(int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(call_base), int(call) & 0xFFFFFFFF, int(layer_id), int(sample0), 0)
+    out = torch.empty((S, n), dtype=torch.float32, device=device)
+    fn = _lib.lib().bt_rng_normal_fill if kind == "normal" else _lib.lib().bt_rng_sign_fill
+    _lib.check(fn(C.byref(R), tensor_id, S, n, out.data_ptr(), _lib.stream_ptr()))
+    return out
+
+
+def mc_epilogue(logits):
+    """logits [S, B, C] -> packed [B*C + B + B*C] = [sum_s softmax | sum_s entropy | sum_s logits]."""
+    logits = _lib.dev_f32(logits, "logits")
+    S, B, Cc = logits.shape
+    packed = torch.empty(B * Cc + B + B * Cc, dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.lib().bt_mc_epilogue(S, B, Cc, logits.data_ptr(), packed.data_ptr(), _lib.stream_ptr()))
+    return packed

@@ -1,0 +1,233 @@
+"""The engine behind the four drop-in layer classes: parameter/buffer set-up with the
+reference's names, and a forward that is ONE call into libbtorch_hip.so.
+
+Reference behaviour reproduced (paths under /root/reference/bayesian_torch/layers/):
+  parameters / buffers / init     variational_layers/linear_variational.py:90-144, conv_variational.py:291-351
+  forward(input, return_kl=True)  linear_variational.py:160-204, conv_variational.py:362-407,
+                                  flipout_layers/linear_flipout.py:145-197, conv_flipout.py:370-439
+  kl_loss()                       linear_variational.py:146-158
+Forward is inference-only in this round (no autograd through the fused kernel yet).
+"""
+import ctypes as C
+import warnings
+
+import torch
+from torch.nn import Parameter
+
+from .. import _lib, mc, rng
+from .. import functional as F
+from .base_variational_layer import BaseVariationalLayer_, check_prior_type, get_kernel_size
+
+_warned = [False]
+
+
+class FusedBayesLayer(BaseVariationalLayer_):
+    _kind = "linear"     # or "conv"
+    _flip = False
+    _wname = "weight"    # parameter suffix: mu_weight / mu_kernel
+
+    # ------------------------------------------------------------------ construction
+    def _build(self, wshape, bias, eps_bias_last=False):
+        wn = self._wname
+        n_out = wshape[0]
+        self.register_parameter("mu_" + wn, Parameter(torch.empty(wshape)))
+        self.register_parameter("rho_" + wn, Parameter(torch.empty(wshape)))
+        self.register_buffer("eps_" + wn, torch.zeros(wshape), persistent=False)
+        self.register_buffer("prior_weight_mu", torch.empty(wshape), persistent=False)
+        self.register_buffer("prior_weight_sigma", torch.empty(wshape), persistent=False)
+        if bias:
+            self.mu_bias = Parameter(torch.empty(n_out))
+            self.rho_bias = Parameter(torch.empty(n_out))
+            if not eps_bias_last:
+                self.register_buffer("eps_bias", torch.zeros(n_out), persistent=False)
+            self.register_buffer("prior_bias_mu", torch.empty(n_out), persistent=False)
+            self.register_buffer("prior_bias_sigma", torch.empty(n_out), persistent=False)
+            if eps_bias_last:   # LinearFlipout registers eps_bias after the priors (linear_flipout.py:98-104)
+                self.register_buffer("eps_bias", torch.zeros(n_out), persistent=False)
+        else:
+            self.register_parameter("mu_bias", None)
+            self.register_parameter("rho_bias", None)
+            for b in ("eps_bias", "prior_bias_mu", "prior_bias_sigma"):
+                self.register_buffer(b, None, persistent=False)
+        self._layer_id = rng.new_layer_id()
+        self._last = None
+        self.init_parameters()
+        self.quant_prepare = False
+
+    def _init_scalars(self):
+        mu0, rho0 = self.posterior_mu_init, self.posterior_rho_init
+        if isinstance(mu0, tuple):   # the Reparameterization classes keep 1-tuples (trailing commas in the reference)
+            mu0, rho0 = mu0[0], rho0[0]
+        return mu0, rho0
+
+    def init_parameters(self):
+        mu0, rho0 = self._init_scalars()
+        self.prior_weight_mu.fill_(self.prior_mean)
+        self.prior_weight_sigma.fill_(self.prior_variance)      # "variance" is used as sigma_p, as in the reference
+        self._w("mu").data.normal_(mean=mu0, std=0.1)
+        self._w("rho").data.normal_(mean=rho0, std=0.1)
+        if self.mu_bias is not None:
+            self.prior_bias_mu.fill_(self.prior_mean)
+            self.prior_bias_sigma.fill_(self.prior_variance)
+            self.mu_bias.data.normal_(mean=mu0, std=0.1)
+            self.rho_bias.data.normal_(mean=rho0, std=0.1)
+
+    def prepare(self):
+        raise NotImplementedError("post-training quantisation (QuantStub observers) is outside the MI355X hot path")
+
+    def _w(self, what):
+        return getattr(self, f"{what}_{self._wname}")
+
+    # ------------------------------------------------------------------ KL
+    def _kl_segments(self):
+        segs = [(self._w("mu"), self._w("rho"), self.prior_weight_mu, self.prior_weight_sigma)]
+        if self.mu_bias is not None:
+            segs.append((self.mu_bias, self.rho_bias, self.prior_bias_mu, self.prior_bias_sigma))
+        return segs
+
+    def kl_loss(self):
+        check_prior_type(getattr(self, "prior_type", "normal"))
+        segs = self._kl_segments()
+        return _lib.kl_normal(segs, layer_ids=[0] * len(segs), owner=("layer", self._layer_id))
+
+    # ------------------------------------------------------------------ forward
+    def _conv_desc(self):
+        pad = self.padding
+        if isinstance(pad, str):
+            raise NotImplementedError("string padding modes are not forwarded by dnn_to_bnn and not supported")
+        return dict(stride=get_kernel_size(self.stride, 2), padding=get_kernel_size(pad, 2),
+                    dilation=get_kernel_size(self.dilation, 2), groups=self.groups)
+
+    def _forward(self, x, return_kl=True):
+        if self.dnn_to_bnn_flag:
+            return_kl = False
+        ctx = mc.current()
+        collect = ctx is not None and ctx.collect_kl
+        want_kl = return_kl or collect
+        if want_kl:
+            check_prior_type(getattr(self, "prior_type", "normal"))
+        x = _lib.dev_f32(x, "input")
+        if torch.is_grad_enabled() and self._w("mu").requires_grad and not _warned[0]:
+            _warned[0] = True
+            warnings.warn("bayesian_torch_amd: the fused forward is inference-only in this build; outputs carry no autograd graph")
+        lead = None
+        if self._kind == "linear":
+            if x.shape[-1] != self.in_features:
+                raise RuntimeError(f"{type(self).__name__}: expected last dim {self.in_features}, got {tuple(x.shape)}")
+            if x.dim() != 2:
+                if ctx is not None:
+                    raise RuntimeError("MC batching needs [N, features] inputs for Linear layers")
+                lead = tuple(x.shape[:-1])
+                x = x.reshape(-1, self.in_features)
+            conv = None
+        else:
+            if x.dim() != 4 or x.shape[1] != self.in_channels:
+                raise RuntimeError(f"{type(self).__name__}: expected [N, {self.in_channels}, H, W], got {tuple(x.shape)}")
+            conv = self._conv_desc()
+        if x.shape[0] == 0:
+            raise RuntimeError("empty batch")
+        if ctx is None:
+            S, shared = 1, True
+        else:
+            S = ctx.S
+            if x.shape[0] == ctx.batch:
+                shared = True
+            elif x.shape[0] == S * ctx.batch:
+                shared = False
+            else:
+                raise RuntimeError(f"inside mc_samples(S={S}, batch={ctx.batch}) a Bayesian layer got batch {x.shape[0]}")
+        B = x.shape[0] // (1 if shared else S)
+
+        sample0 = 0 if ctx is None else ctx.sample0
+        call_base = None if ctx is None else ctx.call_base
+        call, seed = rng.next_call(), rng.seed()
+        draw = self._draw_torch(x, S, B, conv) if rng.get_mode() == "torch" else {}
+        priors = (self.prior_weight_mu, self.prior_weight_sigma, self.prior_bias_mu, self.prior_bias_sigma) if want_kl else None
+        out, kl = F.fused_forward(x, self._w("mu"), self._w("rho"), self.mu_bias, self.rho_bias, flip=self._flip, conv=conv,
+                                  S=S, shared_x=shared, priors=priors, eps_w=draw.get("eps_w"), eps_b=draw.get("eps_b"),
+                                  sign_in=draw.get("sign_in"), sign_out=draw.get("sign_out"), seed=seed, call=call,
+                                  layer_id=self._layer_id, sample0=sample0, call_base=call_base, want_kl=want_kl,
+                                  workspace_owner=("layer", self._layer_id))
+        self._last = dict(draw=draw or None, rng=(seed, call_base, call, self._layer_id, sample0), S=S,
+                          x_shape=(B,) + tuple(x.shape[1:]), out_shape=(B,) + tuple(out.shape[1:]))
+        if lead is not None:
+            out = out.reshape(lead + (self.out_features,))
+        if collect:
+            ctx.kls.append(kl)
+        return (out, kl) if return_kl else out
+
+    # ------------------------------------------------------------------ draws
+    def _draw_torch(self, x, S, B, conv):
+        """Parity mode: draw with torch's generator on the input device in the reference's order."""
+        dev = x.device
+        eps_w_buf = getattr(self, "eps_" + self._wname)
+        has_b = self.mu_bias is not None
+        xs = (S, B) + tuple(x.shape[1:])
+        if conv is None:
+            os_ = (S, B, self.out_features)
+        else:
+            kh, kw = eps_w_buf.shape[2], eps_w_buf.shape[3]
+            os_ = (S, B, self.out_channels) + F.conv_out_hw(x.shape[2], x.shape[3], kh, kw, *conv["stride"], *conv["padding"], *conv["dilation"])
+
+        def eps():
+            if S == 1:
+                ew = eps_w_buf.data.normal_()
+                eb = self.eps_bias.data.normal_() if has_b else None
+            else:
+                ew = torch.empty((S,) + tuple(eps_w_buf.shape), device=dev).normal_()
+                eb = torch.empty((S, eps_w_buf.shape[0]), device=dev).normal_() if has_b else None
+            return ew, eb
+
+        d = {}
+        if not self._flip:
+            d["eps_w"], d["eps_b"] = eps()
+        elif self._kind == "conv":      # s_in, s_out, eps_kernel, eps_bias  (conv_flipout.py:385-402)
+            d["sign_in"] = torch.empty(xs, device=dev).uniform_(-1, 1).sign_()
+            d["sign_out"] = torch.empty(os_, device=dev).uniform_(-1, 1).sign_()
+            d["eps_w"], d["eps_b"] = eps()
+        else:                            # eps_weight, eps_bias, s_in, s_out  (linear_flipout.py:149-170)
+            d["eps_w"], d["eps_b"] = eps()
+            d["sign_in"] = torch.empty(xs, device=dev).uniform_(-1, 1).sign_()
+            d["sign_out"] = torch.empty(os_, device=dev).uniform_(-1, 1).sign_()
+        return d
+
+    def materialize_last_draw(self):
+        """The draw the last forward used, as tensors: eps_w [S, *w], eps_b [S, Co], and for Flipout
+        sign_in [S, B, ...], sign_out [S, B, ...].  In 'torch' mode these are the tensors that were
+        read; in 'philox' mode they are regenerated from the same counters (bt_rng_*_fill)."""
+        if self._last is None:
+            raise RuntimeError("no forward has run yet")
+        st = self._last
+        S = st["S"]
+        wshape = tuple(self._w("mu").shape)
+        if st["draw"] is not None:
+            d = st["draw"]
+            res = dict(eps_w=d["eps_w"].reshape((S,) + wshape))
+            if d.get("eps_b") is not None:
+                res["eps_b"] = d["eps_b"].reshape(S, -1)
+            for k in ("sign_in", "sign_out"):
+                if d.get(k) is not None:
+                    res[k] = d[k]
+            return res
+        seed, call_base, call, lid, sample0 = st["rng"]
+        if call_base is not None:
+            raise RuntimeError("draws made under a graph call_base cannot be replayed after the word advanced")
+        dev = self._w("mu").device
+        R = _lib.bt_rng(seed, None, call, lid, sample0, 0)
+        L = _lib.lib()
+        nw = self._w("mu").numel()
+        res = {}
+        e = torch.empty((S,) + wshape, device=dev)
+        _lib.check(L.bt_rng_normal_fill(C.byref(R), 0, S, nw, e.data_ptr(), _lib.stream_ptr()))
+        res["eps_w"] = e
+        if self.mu_bias is not None:
+            eb = torch.empty((S, wshape[0]), device=dev)
+            _lib.check(L.bt_rng_normal_fill(C.byref(R), 1, S, wshape[0], eb.data_ptr(), _lib.stream_ptr()))
+            res["eps_b"] = eb
+        if self._flip:
+            si = torch.empty((S,) + st["x_shape"], device=dev)
+            so = torch.empty((S,) + st["out_shape"], device=dev)
+            _lib.check(L.bt_rng_sign_fill(C.byref(R), 2, S, si[0].numel(), si.data_ptr(), _lib.stream_ptr()))
+            _lib.check(L.bt_rng_sign_fill(C.byref(R), 3, S, so[0].numel(), so.data_ptr(), _lib.stream_ptr()))
+            res["sign_in"], res["sign_out"] = si, so
+        return res

@@ -1,0 +1,2 @@
+from .conv_flipout import *
+from .linear_flipout import *

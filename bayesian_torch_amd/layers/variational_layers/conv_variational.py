@@ -1,0 +1,30 @@
+"""``Conv2dReparameterization`` -- drop-in for reference
+``layers/variational_layers/conv_variational.py:234-407`` on the fused implicit-GEMM HIP kernel
+(bt_reparam_conv2d_fwd).  Conv1d/3d/Transpose/Multivariate variants are outside this build's scope."""
+from .._fused import FusedBayesLayer
+from ..base_variational_layer import get_kernel_size
+
+__all__ = ["Conv2dReparameterization"]
+
+
+class Conv2dReparameterization(FusedBayesLayer):
+    _kind, _flip, _wname = "conv", False, "kernel"
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 prior_mean=0, prior_variance=1, prior_type=None, posterior_mu_init=0, posterior_rho_init=-3.0, bias=True):
+        super().__init__()
+        if in_channels % groups != 0:
+            raise ValueError('invalid in_channels size')
+        if out_channels % groups != 0:
+            raise ValueError('invalid in_channels size')      # sic: same message as the reference
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation, self.groups = kernel_size, stride, padding, dilation, groups
+        self.prior_mean, self.prior_variance, self.prior_type = prior_mean, prior_variance, prior_type
+        self.posterior_mu_init = (posterior_mu_init,)
+        self.posterior_rho_init = (posterior_rho_init,)
+        self.bias = bias
+        kh, kw = get_kernel_size(kernel_size, 2)
+        self._build((out_channels, in_channels // groups, kh, kw), bias)
+
+    def forward(self, input, return_kl=True):
+        return self._forward(input, return_kl)

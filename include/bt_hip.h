@@ -1,0 +1,153 @@
+/*
+ * bt_hip.h -- C ABI of libbtorch_hip.so: the MI355X (gfx950) implementation of
+ * bayesian-torch's stochastic variational-layer forward + KL hot path.
+ *
+ * The reference (godhj93/bayesian-torch) has no FFI of its own: the path is a
+ * chain of ATen calls inside four nn.Module.forward() methods.  Each entry point
+ * below replaces one such chain; the Python layer classes in
+ * bayesian_torch_amd/layers/ bind them with ctypes (INTEGRATION.md shows the
+ * stub a maintainer of the reference would add).  Citations are relative to
+ * /root/reference/bayesian_torch/.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless it says "host";
+ *   - no allocation, no host synchronisation, no global state inside a call
+ *     (graph-capturable); work is enqueued on `stream` (a hipStream_t);
+ *   - return 0 on success, <0 on error (BT_ERR_*); bt_last_error_string() gives
+ *     the text for the calling thread;
+ *   - `S` MC samples are computed per call: out is [S][...]; sample s uses global
+ *     sample id rng.sample0 + s, so results do not depend on how samples are
+ *     split over calls, streams or ranks;
+ *   - draws: when an eps_* / sign_* pointer is non-NULL the kernel READS the draw
+ *     (parity mode: the caller supplies what torch's generator produced); when it
+ *     is NULL the kernel generates it on chip from `rng` (Philox4x32-10 + Box-Muller
+ *     for eps, a Philox-keyed integer hash for the Flipout signs) and nothing
+ *     weight-sized or activation-sized is written to HBM besides `out`;
+ *   - kl_out: NULL to skip; otherwise receives kl_weight + kl_bias of the layer
+ *     (a function of the parameters only -- computed once, not per sample);
+ *   - workspace: BT_WORKSPACE_BYTES device bytes per in-flight call, zero-filled
+ *     once by the caller; calls leave it zeroed.
+ */
+#ifndef BT_HIP_H
+#define BT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BT_VERSION 100
+#define BT_WORKSPACE_BYTES 65536
+
+#define BT_OK 0
+#define BT_ERR_BAD_ARG (-1)
+#define BT_ERR_UNSUPPORTED (-2)
+#define BT_ERR_WORKSPACE (-3)
+#define BT_ERR_HIP_BASE (-1000) /* -(1000 + hipError_t) */
+
+typedef void *bt_stream_t; /* hipStream_t */
+
+/* Counter-based RNG coordinates; used only for draws whose pointer is NULL. */
+typedef struct bt_rng {
+  uint64_t seed;                 /* Philox key */
+  const uint32_t *call_base_dev; /* optional DEVICE word added to `call` when the kernel runs: lets a captured
+                                    hipGraph draw fresh eps on every replay (advance the word between replays) */
+  uint32_t call;                 /* advance once per forward call (a fresh draw per call) */
+  uint32_t layer_id;             /* < 2^28: distinct per Bayesian layer of a model */
+  uint32_t sample0;              /* global id of this call's first MC sample */
+  uint32_t reserved;
+} bt_rng;
+
+/* Variational parameters and priors of one layer. weight is [Co][K] row-major
+ * (Linear: K = in_features; Conv2d: K = (Ci/groups)*kh*kw, i.e. the native
+ * [Co][Ci/groups][kh][kw] tensor).  Priors are full per-element tensors, read at
+ * call time (users overwrite them: utils/util.py:102-117); only read when
+ * kl_out != NULL. */
+typedef struct bt_params {
+  const float *mu_w, *rho_w;
+  const float *mu_b, *rho_b; /* [Co] or both NULL */
+  const float *prior_mu_w, *prior_sigma_w;
+  const float *prior_mu_b, *prior_sigma_b;
+} bt_params;
+
+/* Injected draws (NULL => generate on chip). Layouts: eps_w [S][Co*K],
+ * eps_b [S][Co], sign_in [S][elements of one sample's x], sign_out
+ * [S][elements of one sample's out]; sign values are the fp32 +1/-1/0 that
+ * torch's uniform_(-1,1).sign() yields. */
+typedef struct bt_draws {
+  const float *eps_w, *eps_b;
+  const float *sign_in, *sign_out; /* Flipout only */
+  bt_rng rng;
+} bt_draws;
+
+typedef struct bt_conv2d_geom {
+  int32_t B, Ci, H, W;    /* input  [B][Ci][H][W]  (NCHW) */
+  int32_t Co, kh, kw;     /* weight [Co][Ci/groups][kh][kw] */
+  int32_t sh, sw, ph, pw, dh, dw, groups;
+} bt_conv2d_geom;
+
+int bt_version(void);
+const char *bt_last_error_string(void);
+
+/* a5: LinearReparameterization.forward  (layers/variational_layers/linear_variational.py:160-181)
+ *   out[s][b][o] = sum_k x_s[b][k] * (mu_w + log1p(exp(rho_w)) * eps_w[s])[o][k] + (mu_b + log1p(exp(rho_b)) * eps_b[s])[o]
+ * x_sample_stride: 0 when all S samples share x [B][In]; else elements between samples (B*In). */
+int bt_reparam_linear_fwd(int32_t B, int32_t In, int32_t Out, int32_t S,
+                          const float *x, int64_t x_sample_stride,
+                          const bt_params *p, const bt_draws *d,
+                          float *out /* [S][B][Out] */, float *kl_out /* [1] or NULL */,
+                          void *workspace, size_t workspace_bytes, bt_stream_t stream);
+
+/* a8: Conv2dReparameterization.forward  (layers/variational_layers/conv_variational.py:362-385)
+ *   F.conv2d(x_s, mu + log1p(exp(rho)) * eps[s], bias_s, stride, padding, dilation, groups) as an implicit GEMM. */
+int bt_reparam_conv2d_fwd(const bt_conv2d_geom *g, int32_t S,
+                          const float *x, int64_t x_sample_stride,
+                          const bt_params *p, const bt_draws *d,
+                          float *out /* [S][B][Co][Ho][Wo] */, float *kl_out,
+                          void *workspace, size_t workspace_bytes, bt_stream_t stream);
+
+/* a9: LinearFlipout.forward  (layers/flipout_layers/linear_flipout.py:145-174)
+ *   out = x W_mu^T + mu_b + ((x o s_in) (sigma o eps)^T + sigma_b o eps_b) o s_out  -- both contractions share one x tile. */
+int bt_flipout_linear_fwd(int32_t B, int32_t In, int32_t Out, int32_t S,
+                          const float *x, int64_t x_sample_stride,
+                          const bt_params *p, const bt_draws *d,
+                          float *out, float *kl_out,
+                          void *workspace, size_t workspace_bytes, bt_stream_t stream);
+
+/* a10: Conv2dFlipout.forward  (layers/flipout_layers/conv_flipout.py:370-417) */
+int bt_flipout_conv2d_fwd(const bt_conv2d_geom *g, int32_t S,
+                          const float *x, int64_t x_sample_stride,
+                          const bt_params *p, const bt_draws *d,
+                          float *out, float *kl_out,
+                          void *workspace, size_t workspace_bytes, bt_stream_t stream);
+
+/* a1/a6/a12: kl_div 'normal' branch + kl_loss() + get_kl_loss()
+ * (layers/base_variational_layer.py:68-72, linear_variational.py:146-158, models/dnn_to_bnn.py:157-165)
+ *   kl_out[0] = sum_seg mean_i( log sp - log sq + (sq^2 + (mq - mp)^2) / (2 sp^2) - 0.5 ),  sq = log1p(exp(rho))
+ * one launch over up to BT_KL_MAX_SEGMENTS tensors (a layer's weight and bias are two segments;
+ * a whole model's layers can go in one call). Segment arrays are HOST arrays. */
+#define BT_KL_MAX_SEGMENTS 64
+#define BT_KL_RHO_IS_SIGMA 1u /* flags: the `rho` arrays already hold sigma (kl_div() called directly) */
+int bt_kl_normal(int32_t n_segments, const float *const *mu, const float *const *rho,
+                 const float *const *prior_mu, const float *const *prior_sigma, const int64_t *numel,
+                 const int32_t *layer_of_segment /* host, non-decreasing, or NULL: the fp32 sum is formed as
+                                                    sum_layers( sum_{segments of layer} mean ) like get_kl_loss */,
+                 uint32_t flags, float *kl_out /* [1] */, void *workspace, size_t workspace_bytes, bt_stream_t stream);
+
+/* The on-chip draws, materialised (test / replay hook: the fused kernels never call these).
+ * They emit exactly the stream the fused kernels consume for (rng, tensor_id):
+ * tensor_id 0 = eps_w, 1 = eps_b, 2 = sign_in, 3 = sign_out. out is [S][n]. */
+int bt_rng_normal_fill(const bt_rng *rng, uint32_t tensor_id, int32_t S, int64_t n, float *out, bt_stream_t stream);
+int bt_rng_sign_fill(const bt_rng *rng, uint32_t tensor_id, int32_t S, int64_t n, float *out, bt_stream_t stream);
+int bt_rng_philox_raw(uint64_t seed, const uint32_t ctr[4], uint32_t out_host[4]); /* host-side Philox4x32-10 KAT hook */
+
+/* MC epilogue (examples/main_bayesian_cifar_dnn2bnn.py:551-557 and :402-412): from logits [S][B][C]
+ * accumulate into packed[B*C + B + B*C] = [sum_s softmax | sum_s entropy | sum_s logits] (overwrites). */
+int bt_mc_epilogue(int32_t S, int32_t B, int32_t C, const float *logits, float *packed, bt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BT_HIP_H */
