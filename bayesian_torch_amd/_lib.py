@@ -32,6 +32,11 @@ class bt_draws(C.Structure):
     _fields_ = [("eps_w", _vp), ("eps_b", _vp), ("sign_in", _vp), ("sign_out", _vp), ("rng", bt_rng)]
 
 
+class bt_epilogue(C.Structure):
+    _fields_ = [("scale", _vp), ("shift", _vp), ("residual", _vp), ("residual_sample_stride", C.c_int64), ("relu", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class bt_conv2d_geom(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "Ci", "H", "W", "Co", "kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw", "groups")]
 
@@ -39,7 +44,7 @@ class bt_conv2d_geom(C.Structure):
 _lib = None
 _lock = threading.Lock()
 
-_FWD_TAIL = [_vp, C.c_int64, C.POINTER(bt_params), C.POINTER(bt_draws), _vp, _vp, _vp, C.c_size_t, _vp]
+_FWD_TAIL = [_vp, C.c_int64, C.POINTER(bt_params), C.POINTER(bt_draws), C.POINTER(bt_epilogue), _vp, _vp, _vp, C.c_size_t, _vp]
 _PROTOS = {
     "bt_version": (C.c_int, []),
     "bt_last_error_string": (C.c_char_p, []),

@@ -10,7 +10,7 @@ int launch_flipout(bool linear, FwdArgs& a, hipStream_t stream);
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const float* x, int64_t x_sample_stride, const bt_params* p,
-               const bt_draws* d, float* out, float* kl_out, void* ws, size_t ws_bytes, bt_stream_t stream, const char* who) {
+               const bt_draws* d, const bt_epilogue* ep, float* out, float* kl_out, void* ws, size_t ws_bytes, bt_stream_t stream, const char* who) {
   char msg[256];
   auto bad = [&](const char* what) {
     snprintf(msg, sizeof(msg), "%s: %s", who, what);
@@ -34,6 +34,8 @@ static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const flo
   }
   if (p->mu_b == nullptr && d->eps_b) return bad("eps_b given for a layer without bias");
   if (!flip && (d->sign_in || d->sign_out)) return bad("sign tensors are Flipout-only");
+  if (ep && ((ep->scale == nullptr) != (ep->shift == nullptr))) return bad("epilogue scale and shift must both be given or both be NULL");
+  if (ep && ep->residual_sample_stride < 0) return bad("negative residual_sample_stride");
 
   const int Ho = (g.H + 2 * g.ph - g.dh * (g.kh - 1) - 1) / g.sh + 1;
   const int Wo = (g.W + 2 * g.pw - g.dw * (g.kw - 1) - 1) / g.sw + 1;
@@ -66,6 +68,7 @@ static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const flo
   a.x_vec = linear && ((K & 3) == 0) && al16(x) && ((x_sample_stride & 3) == 0) && (!d->sign_in || al16(d->sign_in));
   a.do_kl = kl_out != nullptr;
   a.seed_lo = (uint32_t)d->rng.seed, a.seed_hi = (uint32_t)(d->rng.seed >> 32);
+  if (ep) a.ep_scale = ep->scale, a.ep_shift = ep->shift, a.ep_res = ep->residual, a.ep_res_stride = ep->residual_sample_stride, a.ep_relu = ep->relu;
   a.call = d->rng.call, a.call_base = d->rng.call_base_dev, a.layer_id = d->rng.layer_id, a.sample0 = d->rng.sample0;
   return flip ? launch_flipout(linear, a, (hipStream_t)stream) : launch_reparam(linear, a, (hipStream_t)stream);
 }
@@ -79,22 +82,22 @@ static bt_conv2d_geom linear_geom(int B, int In, int Out) {
 }  // namespace bt
 
 extern "C" int bt_reparam_linear_fwd(int32_t B, int32_t In, int32_t Out, int32_t S, const float* x, int64_t x_sample_stride,
-                                     const bt_params* p, const bt_draws* d, float* out, float* kl_out, void* ws, size_t ws_bytes,
+                                     const bt_params* p, const bt_draws* d, const bt_epilogue* ep, float* out, float* kl_out, void* ws, size_t ws_bytes,
                                      bt_stream_t stream) {
-  return bt::run(false, true, bt::linear_geom(B, In, Out), S, x, x_sample_stride, p, d, out, kl_out, ws, ws_bytes, stream, "bt_reparam_linear_fwd");
+  return bt::run(false, true, bt::linear_geom(B, In, Out), S, x, x_sample_stride, p, d, ep, out, kl_out, ws, ws_bytes, stream, "bt_reparam_linear_fwd");
 }
 extern "C" int bt_flipout_linear_fwd(int32_t B, int32_t In, int32_t Out, int32_t S, const float* x, int64_t x_sample_stride,
-                                     const bt_params* p, const bt_draws* d, float* out, float* kl_out, void* ws, size_t ws_bytes,
+                                     const bt_params* p, const bt_draws* d, const bt_epilogue* ep, float* out, float* kl_out, void* ws, size_t ws_bytes,
                                      bt_stream_t stream) {
-  return bt::run(true, true, bt::linear_geom(B, In, Out), S, x, x_sample_stride, p, d, out, kl_out, ws, ws_bytes, stream, "bt_flipout_linear_fwd");
+  return bt::run(true, true, bt::linear_geom(B, In, Out), S, x, x_sample_stride, p, d, ep, out, kl_out, ws, ws_bytes, stream, "bt_flipout_linear_fwd");
 }
 extern "C" int bt_reparam_conv2d_fwd(const bt_conv2d_geom* g, int32_t S, const float* x, int64_t x_sample_stride, const bt_params* p,
-                                     const bt_draws* d, float* out, float* kl_out, void* ws, size_t ws_bytes, bt_stream_t stream) {
+                                     const bt_draws* d, const bt_epilogue* ep, float* out, float* kl_out, void* ws, size_t ws_bytes, bt_stream_t stream) {
   if (!g) return bt::set_error(BT_ERR_BAD_ARG, "bt_reparam_conv2d_fwd: null geometry");
-  return bt::run(false, false, *g, S, x, x_sample_stride, p, d, out, kl_out, ws, ws_bytes, stream, "bt_reparam_conv2d_fwd");
+  return bt::run(false, false, *g, S, x, x_sample_stride, p, d, ep, out, kl_out, ws, ws_bytes, stream, "bt_reparam_conv2d_fwd");
 }
 extern "C" int bt_flipout_conv2d_fwd(const bt_conv2d_geom* g, int32_t S, const float* x, int64_t x_sample_stride, const bt_params* p,
-                                     const bt_draws* d, float* out, float* kl_out, void* ws, size_t ws_bytes, bt_stream_t stream) {
+                                     const bt_draws* d, const bt_epilogue* ep, float* out, float* kl_out, void* ws, size_t ws_bytes, bt_stream_t stream) {
   if (!g) return bt::set_error(BT_ERR_BAD_ARG, "bt_flipout_conv2d_fwd: null geometry");
-  return bt::run(true, false, *g, S, x, x_sample_stride, p, d, out, kl_out, ws, ws_bytes, stream, "bt_flipout_conv2d_fwd");
+  return bt::run(true, false, *g, S, x, x_sample_stride, p, d, ep, out, kl_out, ws, ws_bytes, stream, "bt_flipout_conv2d_fwd");
 }

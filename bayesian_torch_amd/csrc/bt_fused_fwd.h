@@ -39,6 +39,9 @@ struct FwdArgs {
   int do_kl;
   uint32_t seed_lo, seed_hi, call, layer_id, sample0;
   const uint32_t* call_base;  // device word added to `call` (fresh draws on graph replay), or null
+  const float *ep_scale, *ep_shift, *ep_res;  // fused output stage (bt_epilogue)
+  long long ep_res_stride;
+  int ep_relu;
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2). Give every XCD a
@@ -355,6 +358,7 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdArgs a) {
 
   float* const out_s = a.out + (long long)s * a.out_elems;
   const float* const sout_s = (FLIP && a.sign_out) ? a.sign_out + (long long)s * a.out_elems : nullptr;
+  const float* const res_s = a.ep_res ? a.ep_res + (long long)s * a.ep_res_stride : nullptr;
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     int b_col = 0, p_col = 0;
@@ -385,6 +389,12 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdArgs a) {
             const float so = sout_s ? sout_s[oidx] : hash_sign(skey_out, (uint32_t)oidx);
             v = __fadd_rn(v, __fmul_rn(__fadd_rn(acc[NW - 1][i][j][r], bias1[co_l]), so));
           }
+          if (a.ep_scale) {
+            const int co = g * a.Cog + n0 + co_l;
+            v = __fadd_rn(__fmul_rn(v, a.ep_scale[co]), a.ep_shift[co]);
+          }
+          if (res_s) v = __fadd_rn(v, res_s[oidx]);
+          if (a.ep_relu) v = fmaxf(v, 0.f);
           out_s[oidx] = v;
         }
       }

@@ -13,15 +13,18 @@ def conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, dh, dw):
 
 def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=None, S=1, shared_x=True,
                   priors=None, eps_w=None, eps_b=None, sign_in=None, sign_out=None,
-                  seed=0, call=0, layer_id=0, sample0=0, call_base=None, want_kl=False, workspace_owner="functional"):
+                  seed=0, call=0, layer_id=0, sample0=0, call_base=None, want_kl=False, workspace_owner="functional",
+                  post_scale=None, post_shift=None, residual=None, relu=False):
     """x: [B, In] (conv=None) or [B, Ci, H, W]; when ``shared_x`` is False x holds S stacked batches
     ([S*B, ...]).  conv: dict(stride=(sh,sw), padding=(ph,pw), dilation=(dh,dw), groups=g) for Conv2d.
     priors: (prior_mu_w, prior_sigma_w, prior_mu_b, prior_sigma_b) -- required when want_kl.
     eps_*/sign_*: injected draws with a leading S axis, or None for the on-chip generators.
-    Returns (out [S*B, ...], kl or None)."""
+    post_scale/post_shift [Co], residual ([S*B, ...] like out, or [B, ...] shared), relu: fused output stage
+    (v*scale+shift, +residual, max(.,0)).  Returns (out [S*B, ...], kl or None)."""
     x = _lib.dev_f32(x, "input")
     dev = x.device
-    tens = dict(mu_w=mu_w, rho_w=rho_w, mu_b=mu_b, rho_b=rho_b, eps_w=eps_w, eps_b=eps_b, sign_in=sign_in, sign_out=sign_out)
+    tens = dict(mu_w=mu_w, rho_w=rho_w, mu_b=mu_b, rho_b=rho_b, eps_w=eps_w, eps_b=eps_b, sign_in=sign_in, sign_out=sign_out,
+                post_scale=post_scale, post_shift=post_shift, residual=residual)
     for k, t in tens.items():
         t = _lib.dev_f32(t, k)
         if t is not None and t.device != dev:
@@ -61,7 +64,18 @@ def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=Non
                        _lib.ptr(pr[0]), _lib.ptr(pr[1]), _lib.ptr(pr[2]), _lib.ptr(pr[3]))
     R = _lib.bt_rng(int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(call_base), int(call) & 0xFFFFFFFF, int(layer_id), int(sample0), 0)
     D = _lib.bt_draws(_lib.ptr(tens["eps_w"]), _lib.ptr(tens["eps_b"]), _lib.ptr(tens["sign_in"]), _lib.ptr(tens["sign_out"]), R)
-    tail_args = (x.data_ptr(), 0 if shared_x else x_elems, C.byref(P), C.byref(D), out.data_ptr(), _lib.ptr(kl), _lib.ptr(ws),
+    E = None
+    if tens["post_scale"] is not None or tens["residual"] is not None or relu:
+        res, rstride = tens["residual"], 0
+        if res is not None:
+            if res.numel() == out.numel():
+                rstride = out.numel() // S
+            elif res.numel() * S != out.numel():
+                raise RuntimeError(f"residual has {res.numel()} elements, out has {out.numel()} (S={S})")
+        if tens["post_scale"] is not None and (tens["post_scale"].numel() != Co or tens["post_shift"] is None or tens["post_shift"].numel() != Co):
+            raise RuntimeError("post_scale / post_shift must both have Co elements")
+        E = C.byref(_lib.bt_epilogue(_lib.ptr(tens["post_scale"]), _lib.ptr(tens["post_shift"]), _lib.ptr(res), rstride, 1 if relu else 0, 0))
+    tail_args = (x.data_ptr(), 0 if shared_x else x_elems, C.byref(P), C.byref(D), E, out.data_ptr(), _lib.ptr(kl), _lib.ptr(ws),
                  _lib.WORKSPACE_BYTES if want_kl else 0, _lib.stream_ptr())
     L = _lib.lib()
     if conv is None:

@@ -31,6 +31,8 @@ class _Basic(nn.Module):
 
     def forward(self, x):
         skip = x if self.downsample is None else self.downsample(x)
+        if getattr(self, "fused", False):          # fuse_inference(): bn/relu/add live in the conv kernels' output stage
+            return self.conv2(self.conv1(x), residual=skip)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
         return self.relu(y + skip)
@@ -53,6 +55,8 @@ class _Bottle(nn.Module):
 
     def forward(self, x):
         skip = x if self.downsample is None else self.downsample(x)
+        if getattr(self, "fused", False):
+            return self.conv3(self.conv2(self.conv1(x)), residual=skip)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.relu(self.bn2(self.conv2(y)))
         y = self.bn3(self.conv3(y))
@@ -86,7 +90,10 @@ class ResNet(nn.Module):
         return nn.Sequential(*mods)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        if getattr(self, "fused", False):
+            x = self.maxpool(self.conv1(x))
+        else:
+            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
@@ -130,3 +137,21 @@ def fill_bayes_params(model, seed, mu_std=0.1, rho_mean=-3.0, rho_std=0.1):
                 v = torch.randn(p.shape, generator=g)
                 v = v * (mu_std if nm.startswith("mu") else rho_std) + (0.0 if nm.startswith("mu") else rho_mean)
                 p.copy_(v.to(p.device))
+
+
+def fuse_inference(model):
+    """Fold every BatchNorm / ReLU / residual add of a converted ResNet into the Bayesian convs' output stage
+    (bayesian_torch_amd.fuse).  The model must be converted (dnn_to_bnn), on its device and in eval()."""
+    from ..fuse import fold_pair
+    fold_pair(model.conv1, model.bn1, relu=True)
+    for stage in (model.layer1, model.layer2, model.layer3, model.layer4):
+        for blk in stage:
+            last = 3 if isinstance(blk, _Bottle) else 2
+            for i in range(1, last + 1):
+                fold_pair(getattr(blk, f"conv{i}"), getattr(blk, f"bn{i}"), relu=True)   # the last ReLU runs after the fused add
+            if blk.downsample is not None:
+                fold_pair(blk.downsample[0], blk.downsample[1], relu=False)
+                blk.downsample[1] = nn.Identity()
+            blk.fused = True
+    model.fused = True
+    return model

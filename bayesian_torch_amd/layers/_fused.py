@@ -51,6 +51,10 @@ class FusedBayesLayer(BaseVariationalLayer_):
                 self.register_buffer(b, None, persistent=False)
         self._layer_id = rng.new_layer_id()
         self._last = None
+        self.post_relu = False    # fused output stage, set by bayesian_torch_amd.fuse (inference-time folding)
+        self.register_buffer("post_scale", None, persistent=False)
+        self.register_buffer("post_shift", None, persistent=False)
+        self.inject_draw = None   # test hook: dict(eps_w [S,*w], eps_b, sign_in, sign_out) consumed instead of a fresh draw
         self.init_parameters()
         self.quant_prepare = False
 
@@ -98,7 +102,7 @@ class FusedBayesLayer(BaseVariationalLayer_):
         return dict(stride=get_kernel_size(self.stride, 2), padding=get_kernel_size(pad, 2),
                     dilation=get_kernel_size(self.dilation, 2), groups=self.groups)
 
-    def _forward(self, x, return_kl=True):
+    def _forward(self, x, return_kl=True, residual=None):
         if self.dnn_to_bnn_flag:
             return_kl = False
         ctx = mc.current()
@@ -141,13 +145,19 @@ class FusedBayesLayer(BaseVariationalLayer_):
         sample0 = 0 if ctx is None else ctx.sample0
         call_base = None if ctx is None else ctx.call_base
         call, seed = rng.next_call(), rng.seed()
-        draw = self._draw_torch(x, S, B, conv) if rng.get_mode() == "torch" else {}
+        if self.inject_draw is not None:
+            draw = {k: v for k, v in self.inject_draw.items() if v is not None}
+            if draw["eps_w"].shape[0] != S:
+                raise RuntimeError(f"inject_draw holds {draw['eps_w'].shape[0]} samples, this call computes {S}")
+        else:
+            draw = self._draw_torch(x, S, B, conv) if rng.get_mode() == "torch" else {}
         priors = (self.prior_weight_mu, self.prior_weight_sigma, self.prior_bias_mu, self.prior_bias_sigma) if want_kl else None
         out, kl = F.fused_forward(x, self._w("mu"), self._w("rho"), self.mu_bias, self.rho_bias, flip=self._flip, conv=conv,
                                   S=S, shared_x=shared, priors=priors, eps_w=draw.get("eps_w"), eps_b=draw.get("eps_b"),
                                   sign_in=draw.get("sign_in"), sign_out=draw.get("sign_out"), seed=seed, call=call,
                                   layer_id=self._layer_id, sample0=sample0, call_base=call_base, want_kl=want_kl,
-                                  workspace_owner=("layer", self._layer_id))
+                                  workspace_owner=("layer", self._layer_id), post_scale=self.post_scale, post_shift=self.post_shift,
+                                  residual=residual, relu=self.post_relu)
         self._last = dict(draw=draw or None, rng=(seed, call_base, call, self._layer_id, sample0), S=S,
                           x_shape=(B,) + tuple(x.shape[1:]), out_shape=(B,) + tuple(out.shape[1:]))
         if lead is not None:

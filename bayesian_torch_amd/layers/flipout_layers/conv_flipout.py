@@ -23,5 +23,5 @@ class Conv2dFlipout(FusedBayesLayer):
         kh, kw = get_kernel_size(kernel_size, 2)
         self._build((out_channels, in_channels // groups, kh, kw), bias)
 
-    def forward(self, x, return_kl=True):
-        return self._forward(x, return_kl)
+    def forward(self, x, return_kl=True, residual=None):
+        return self._forward(x, return_kl, residual)

@@ -17,5 +17,5 @@ class LinearFlipout(FusedBayesLayer):
         self.posterior_mu_init, self.posterior_rho_init = posterior_mu_init, posterior_rho_init
         self._build((out_features, in_features), bias, eps_bias_last=True)
 
-    def forward(self, x, return_kl=True):
-        return self._forward(x, return_kl)
+    def forward(self, x, return_kl=True, residual=None):
+        return self._forward(x, return_kl, residual)

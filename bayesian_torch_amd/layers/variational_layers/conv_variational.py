@@ -26,5 +26,5 @@ class Conv2dReparameterization(FusedBayesLayer):
         kh, kw = get_kernel_size(kernel_size, 2)
         self._build((out_channels, in_channels // groups, kh, kw), bias)
 
-    def forward(self, input, return_kl=True):
-        return self._forward(input, return_kl)
+    def forward(self, input, return_kl=True, residual=None):
+        return self._forward(input, return_kl, residual)

@@ -20,5 +20,5 @@ class LinearReparameterization(FusedBayesLayer):
         self.bias = bias
         self._build((out_features, in_features), bias)
 
-    def forward(self, input, return_kl=True):
-        return self._forward(input, return_kl)
+    def forward(self, input, return_kl=True, residual=None):
+        return self._forward(input, return_kl, residual)

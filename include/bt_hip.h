@@ -88,6 +88,20 @@ typedef struct bt_conv2d_geom {
   int32_t sh, sw, ph, pw, dh, dw, groups;
 } bt_conv2d_geom;
 
+/* Optional fused output stage (inference-time Conv+BN(+add)(+ReLU) folding, SURVEY.md section 8(f) rank 4;
+ * the reference folds BN only in its quantised path, models/bnn_to_qbnn.py:174-196). Applied per output
+ * element after the layer's own result v (bias and Flipout perturbation included):
+ *     v = v * scale[co] + shift[co]   (when scale != NULL; BatchNorm in eval mode is exactly this affine map)
+ *     v = v + residual_s[idx]         (when residual != NULL; same layout as one sample of out)
+ *     v = max(v, 0)                   (when relu != 0)                                                      */
+typedef struct bt_epilogue {
+  const float *scale, *shift;      /* [Co] each, or both NULL */
+  const float *residual;           /* NULL, or [S][elements of one sample's out] / shared when stride is 0 */
+  int64_t residual_sample_stride;  /* elements between samples, or 0 */
+  int32_t relu;
+  int32_t reserved;
+} bt_epilogue;
+
 int bt_version(void);
 const char *bt_last_error_string(void);
 
@@ -96,7 +110,7 @@ const char *bt_last_error_string(void);
  * x_sample_stride: 0 when all S samples share x [B][In]; else elements between samples (B*In). */
 int bt_reparam_linear_fwd(int32_t B, int32_t In, int32_t Out, int32_t S,
                           const float *x, int64_t x_sample_stride,
-                          const bt_params *p, const bt_draws *d,
+                          const bt_params *p, const bt_draws *d, const bt_epilogue *ep /* or NULL */,
                           float *out /* [S][B][Out] */, float *kl_out /* [1] or NULL */,
                           void *workspace, size_t workspace_bytes, bt_stream_t stream);
 
@@ -104,7 +118,7 @@ int bt_reparam_linear_fwd(int32_t B, int32_t In, int32_t Out, int32_t S,
  *   F.conv2d(x_s, mu + log1p(exp(rho)) * eps[s], bias_s, stride, padding, dilation, groups) as an implicit GEMM. */
 int bt_reparam_conv2d_fwd(const bt_conv2d_geom *g, int32_t S,
                           const float *x, int64_t x_sample_stride,
-                          const bt_params *p, const bt_draws *d,
+                          const bt_params *p, const bt_draws *d, const bt_epilogue *ep /* or NULL */,
                           float *out /* [S][B][Co][Ho][Wo] */, float *kl_out,
                           void *workspace, size_t workspace_bytes, bt_stream_t stream);
 
@@ -112,14 +126,14 @@ int bt_reparam_conv2d_fwd(const bt_conv2d_geom *g, int32_t S,
  *   out = x W_mu^T + mu_b + ((x o s_in) (sigma o eps)^T + sigma_b o eps_b) o s_out  -- both contractions share one x tile. */
 int bt_flipout_linear_fwd(int32_t B, int32_t In, int32_t Out, int32_t S,
                           const float *x, int64_t x_sample_stride,
-                          const bt_params *p, const bt_draws *d,
+                          const bt_params *p, const bt_draws *d, const bt_epilogue *ep /* or NULL */,
                           float *out, float *kl_out,
                           void *workspace, size_t workspace_bytes, bt_stream_t stream);
 
 /* a10: Conv2dFlipout.forward  (layers/flipout_layers/conv_flipout.py:370-417) */
 int bt_flipout_conv2d_fwd(const bt_conv2d_geom *g, int32_t S,
                           const float *x, int64_t x_sample_stride,
-                          const bt_params *p, const bt_draws *d,
+                          const bt_params *p, const bt_draws *d, const bt_epilogue *ep /* or NULL */,
                           float *out, float *kl_out,
                           void *workspace, size_t workspace_bytes, bt_stream_t stream);
 
