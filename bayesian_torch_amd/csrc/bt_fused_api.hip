@@ -5,7 +5,9 @@
 
 namespace bt {
 int launch_reparam(bool linear, FwdArgs& a, hipStream_t stream);
+int launch_reparam_inj(bool linear, FwdArgs& a, hipStream_t stream);
 int launch_flipout(bool linear, FwdArgs& a, hipStream_t stream);
+int launch_flipout_inj(bool linear, FwdArgs& a, hipStream_t stream);
 
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
@@ -59,17 +61,26 @@ static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const flo
   a.out_elems = M * g.Co;
   a.w_elems = (long long)g.Co * K;
   // 32-bit index budget of the kernel (tile indices, hashed sign indices, Philox block index)
-  if (M > 0x7FFFFFFFll || K > 0x7FFFFFFFll || a.x_elems > 0xFFFFFFFFll || a.out_elems > 0xFFFFFFFFll || a.w_elems > (1ll << 34))
-    return set_error(BT_ERR_UNSUPPORTED, "fused forward: tensor too large for 32-bit tile indexing");
+  if (M >= (1ll << 30) || K >= (1ll << 30) || a.x_elems >= (1ll << 30) || a.out_elems >= (1ll << 30) || a.w_elems >= (1ll << 30))
+    return set_error(BT_ERR_UNSUPPORTED, "fused forward: a tensor of 2^30 elements or more exceeds the kernel's 32-bit offsets");
   a.M = (int)M, a.K = (int)K, a.S = S;
+  a.T = g.kh * g.kw, a.HW = g.H * g.W;
+  if (a.T > kMaxTaps) return set_error(BT_ERR_UNSUPPORTED, "fused forward: kernels larger than 128 taps are not supported");
+  // pixel-major tiles prune padding taps per output pixel; worth it when images are tiny (2x2 outputs: 4 of 9 taps)
+  a.pixel_major = (!linear && a.HoWo >= 2 && a.HoWo <= 4 && (g.ph > 0 || g.pw > 0)) ? 1 : 0;
   a.x_sample_stride = x_sample_stride;
-  a.w_vec = ((K & 3) == 0) && al16(p->mu_w) && al16(p->rho_w) && (!d->eps_w || al16(d->eps_w)) &&
-            (!kl_out || (al16(p->prior_mu_w) && al16(p->prior_sigma_w)));
+  a.w_vec = linear && ((K & 3) == 0) && al16(p->mu_w) && al16(p->rho_w) && (!d->eps_w || al16(d->eps_w));
   a.x_vec = linear && ((K & 3) == 0) && al16(x) && ((x_sample_stride & 3) == 0) && (!d->sign_in || al16(d->sign_in));
   a.do_kl = kl_out != nullptr;
   a.seed_lo = (uint32_t)d->rng.seed, a.seed_hi = (uint32_t)(d->rng.seed >> 32);
   if (ep) a.ep_scale = ep->scale, a.ep_shift = ep->shift, a.ep_res = ep->residual, a.ep_res_stride = ep->residual_sample_stride, a.ep_relu = ep->relu;
   a.call = d->rng.call, a.call_base = d->rng.call_base_dev, a.layer_id = d->rng.layer_id, a.sample0 = d->rng.sample0;
+  // draws are either all injected or all generated on chip (one compile-time flavour each)
+  const bool inj = d->eps_w != nullptr;
+  const bool all_inj = inj && (!p->mu_b || d->eps_b) && (!flip || (d->sign_in && d->sign_out));
+  const bool none_inj = !d->eps_w && !d->eps_b && !d->sign_in && !d->sign_out;
+  if (!all_inj && !none_inj) return bad("inject all draws of the layer (eps_w, eps_b when biased, both sign tensors for Flipout) or none");
+  if (inj) return flip ? launch_flipout_inj(linear, a, (hipStream_t)stream) : launch_reparam_inj(linear, a, (hipStream_t)stream);
   return flip ? launch_flipout(linear, a, (hipStream_t)stream) : launch_reparam(linear, a, (hipStream_t)stream);
 }
 

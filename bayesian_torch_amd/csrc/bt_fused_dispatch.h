@@ -5,33 +5,65 @@
 
 namespace bt {
 
-template <int BN, int BM, int WAVES_N, bool FLIP, bool LINEAR, bool TRANS>
+template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, bool INJ>
 static int launch_cfg(FwdArgs& a, hipStream_t stream) {
+  auto kern = fused_fwd_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, INJ>;
+  constexpr int lds = fused_lds_bytes<BN, BM, FLIP>();
+  static_assert(lds <= 160 * 1024, "LDS budget of one CU");
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return set_error(BT_ERR_HIP_BASE, "fused forward: hipGetDevice failed");
+  if (!attr_set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return set_error(BT_ERR_HIP_BASE, "fused forward: cannot raise the dynamic LDS limit");
+    attr_set[dev] = true;
+  }
   a.n_tiles = (a.Cog + BN - 1) / BN;
-  a.m_tiles = (a.M + BM - 1) / BM;
+  if (a.pixel_major) {
+    a.mt_per_pixel = (a.B + BM - 1) / BM;
+    a.m_tiles = a.HoWo * a.mt_per_pixel;
+  } else {
+    a.mt_per_pixel = 1;
+    a.m_tiles = (a.M + BM - 1) / BM;
+  }
   const long long total = (long long)a.G * a.n_tiles * a.S * a.m_tiles;
   if (total <= 0 || total > 0x7FFFFFFFll) return set_error(BT_ERR_UNSUPPORTED, "fused forward: grid too large");
-  if (a.do_kl && a.G * a.n_tiles > kMaxSlots) return set_error(BT_ERR_UNSUPPORTED, "fused forward: too many KL slots");
   a.total_blocks = (int)total;
-  hipLaunchKernelGGL((fused_fwd_kernel<BN, BM, WAVES_N, FLIP, LINEAR, TRANS>), dim3((unsigned)total), dim3(256), 0, stream, a);
+  a.kl_slices = total < 4096 ? (int)total : 4096;
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(kThreads), lds, stream, a);
   return check_launch("fused forward");
 }
 
-template <bool FLIP, bool LINEAR, bool TRANS>
-static int pick_tile(FwdArgs& a, hipStream_t stream) {
-  // block tile = BN output channels x BM output positions, 4 waves of 32x32 MFMA tiles.
-  if (a.M <= 32) return launch_cfg<128, 32, 4, FLIP, LINEAR, TRANS>(a, stream);
-  if (a.Cog <= 32) return launch_cfg<32, 128, 1, FLIP, LINEAR, TRANS>(a, stream);
-  if (a.M <= 64) return launch_cfg<64, 64, 2, FLIP, LINEAR, TRANS>(a, stream);
-  if (a.Cog <= 64) return launch_cfg<64, 128, 2, FLIP, LINEAR, TRANS>(a, stream);
-  return launch_cfg<128, 128, 2, FLIP, LINEAR, TRANS>(a, stream);
+static inline long long tiles_for(const FwdArgs& a, int BN, int BM) {
+  const long long nt = (a.Cog + BN - 1) / BN;
+  const long long mt = a.pixel_major ? (long long)a.HoWo * ((a.B + BM - 1) / BM) : (a.M + BM - 1) / BM;
+  return (long long)a.G * nt * a.S * mt;
 }
 
-template <bool FLIP>
+template <bool FLIP, bool LINEAR, bool TRANS, bool INJ>
+static int pick_tile(FwdArgs& a, hipStream_t stream) {
+  // Workgroup tile = BN output channels x BM output positions; 4 consumer waves of (BN/CWN) x (BM/CWM) each.
+  // Wide BM amortises one weight draw over more MFMA work (the producers' VALU budget); a launch should still
+  // offer >= 256 workgroups (one per CU), so tiles shrink when the grid would not fill the chip.
+  constexpr long long kCUs = 256;
+  const int Mdom = a.pixel_major ? a.B : a.M;
+  if (Mdom <= 32) return launch_cfg<128, 32, 4, FLIP, LINEAR, TRANS, INJ>(a, stream);
+  if (Mdom <= 64) return launch_cfg<64, 64, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);
+  if (a.Cog <= 32) return launch_cfg<32, 128, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
+  if constexpr (!FLIP) {  // 256-wide tiles: one accumulator set fits (Flipout carries two)
+    if (Mdom >= 256) {
+      if (tiles_for(a, 64, 256) >= kCUs) return launch_cfg<64, 256, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
+    }
+  }
+  if (a.Cog > 64 && tiles_for(a, 128, 128) >= kCUs) return launch_cfg<128, 128, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);
+  return launch_cfg<64, 128, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);
+}
+
+template <bool FLIP, bool INJ>
 static int launch_flavour(bool linear, FwdArgs& a, hipStream_t stream) {
-  if (linear) return pick_tile<FLIP, true, true>(a, stream);
-  if (a.HoWo == 1) return pick_tile<FLIP, false, true>(a, stream);
-  return pick_tile<FLIP, false, false>(a, stream);
+  if (linear && a.w_vec && a.x_vec) return pick_tile<FLIP, true, true, INJ>(a, stream);   // float4 fast path
+  if (a.HoWo == 1 || a.pixel_major) return pick_tile<FLIP, false, true, INJ>(a, stream);  // incl. any other Linear: a 1x1 conv
+  return pick_tile<FLIP, false, false, INJ>(a, stream);
 }
 
 }  // namespace bt

@@ -2,27 +2,40 @@
 //
 //   D_s[co][m] = sum_k W_s[co][k] * X_s[k][m]      m = (b, ho, wo),  k = (ci, kh, kw)
 //
-//   W_s = mu + log1p(exp(rho)) * eps_s   is synthesised per K-tile straight into LDS (never in HBM):
-//         coalesced float4 loads of (mu, rho) [+ injected eps | on-chip Philox + Box-Muller],
-//         two roundings exactly like the reference (tmp = sigma*eps; w = mu + tmp);
-//   X_s   is the implicit-GEMM (im2col) view of the NCHW input, gathered per K-tile through a small
-//         k -> (offset, dh, dw) table; for Linear it is the row-major activation tile;
-//   the contraction runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain,
-//         rtol 1e-4 with K up to 4608 rules out bf16 inputs and gfx950 has no xf32);
-//   Flipout keeps TWO accumulators over one staged x tile: mean path (mu, x) and perturbation path
-//         (sigma*eps, x o s_in), s_in/s_out applied in registers;
-//   KL    is accumulated by the blocks that own (m-tile 0, sample 0) while (mu, rho) are in registers,
-//         reduced with wave shuffles and finished in fixed order by the last-arriving block;
-//   MC    samples are a grid dimension: one launch computes S samples, (mu, rho) re-reads hit L2.
+// Structure (768 threads = 12 waves per workgroup, one workgroup per CU):
+//   waves 4-11 PRODUCERS  synthesise the next K-stage into LDS while the consumers multiply the current one:
+//       W_s = mu + log1p(exp(rho)) * eps_s  from (mu, rho) [+ injected eps | on-chip Philox4x32-10 + Box-Muller],
+//             two roundings exactly like the reference (tmp = sigma*eps; w = mu + tmp); never written to HBM;
+//       X_s   the implicit-GEMM (im2col) view of the NCHW input (Linear: the row-major activation tile);
+//       Flipout: a second pair of tiles, sigma*eps and x o s_in (signs applied in registers);
+//   waves 0-3  CONSUMERS  only read LDS and issue v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: an exact fp32
+//             FMA chain -- rtol 1e-4 with K up to 4608 rules out bf16 inputs and gfx950 has no xf32); Flipout keeps two
+//             accumulator sets (mean path, perturbation path) over the same staged x tile;
+//   the two roles run on the same SIMDs (matrix pipe and VALU are separate pipes), LDS is double-buffered and
+//   there is ONE workgroup barrier per K-stage.
+// A K-stage is (CC input channels) x (up to 9 ACTIVE taps): taps that can only ever meet zero padding for the
+// tile's output pixels are dropped from the schedule -- no loads, no RNG, no MFMA for them (ResNet18/CIFAR layer4
+// sees 1x1 images: 1 of 9 taps survives).  With pixel-major m-tiles (one output pixel x 128 images) the same
+// pruning applies per pixel (2x2 images: 4 of 9 taps).  Exact: the skipped products are products with zeros.
+// KL is swept cooperatively: every workgroup takes a slice of the flat weight tensor (its consumer waves do it
+// while the producers fill the first stage), wave-shuffle + LDS reduction, one fp64 slot per workgroup, fixed-order
+// finish by the last-arriving workgroup.  MC samples are a grid dimension; (mu, rho) re-reads hit the XCD's L2.
 //
 // Replaces the ATen chains at reference layers/variational_layers/linear_variational.py:163-181,
 // conv_variational.py:366-385, flipout_layers/linear_flipout.py:149-174, conv_flipout.py:376-417.
 #pragma once
+#include <type_traits>
+
 #include "bt_api_internal.h"
 
 namespace bt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBK = 36;        // K rows of one LDS stage (9 taps x 4 channels)
+constexpr int kMaxTaps = 128;  // kh*kw supported by the tap table
+constexpr int kThreads = 768;   // 4 consumer waves (one per SIMD) + 8 producer waves (two per SIMD)
+constexpr int kProducers = 512;
 
 struct FwdArgs {
   const float *x, *mu_w, *rho_w, *mu_b, *rho_b, *pmu_w, *psig_w, *pmu_b, *psig_b;
@@ -33,10 +46,11 @@ struct FwdArgs {
   unsigned* counter;
   long long x_sample_stride, x_elems, out_elems, w_elems;
   int B, Ci, H, W, Co, KH, KW, SH, SW, PH, PW, DH, DW, G;
-  int Ho, Wo, HoWo, M, K, Cig, Cog, S;
+  int Ho, Wo, HoWo, M, K, Cig, Cog, S, T, HW;
   int n_tiles, m_tiles, total_blocks;
-  int w_vec, x_vec;  // float4 paths allowed (K % 4 == 0 and 16-B aligned bases)
-  int do_kl;
+  int pixel_major, mt_per_pixel;  // m-tile = (one output pixel, BM images) instead of BM consecutive (b, ho, wo)
+  int w_vec, x_vec;               // float4 paths allowed (taps == 1, K % 4 == 0, 16-B aligned bases)
+  int do_kl, kl_slices;
   uint32_t seed_lo, seed_hi, call, layer_id, sample0;
   const uint32_t* call_base;  // device word added to `call` (fresh draws on graph replay), or null
   const float *ep_scale, *ep_shift, *ep_res;  // fused output stage (bt_epilogue)
@@ -44,43 +58,56 @@ struct FwdArgs {
   int ep_relu;
 };
 
-// Blocks are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2). Give every XCD a
-// CONTIGUOUS range of the logical block order, which is n-tile-major: an XCD then works on few
-// n-tiles for all samples and m-tiles, so its (mu, rho) working set stays in its own L2.
-// Bijective for any grid size (cdna_hip_programming.md, T1).
+// Blocks are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2). Give every XCD a CONTIGUOUS range of
+// the logical block order, which is n-tile-major: an XCD then works on few n-tiles for all samples and m-tiles, so
+// its (mu, rho) working set stays in its own L2. Bijective for any grid size (cdna_hip_programming.md, T1).
 __device__ __forceinline__ int xcd_remap(int orig, int n) {
   const int q = n >> 3, r = n & 7, xcd = orig & 7, i = orig >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
-template <int BN, int BM, int WAVES_N, bool FLIP, bool LINEAR, bool TRANS>
-__global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdArgs a) {
-  constexpr int BK = 32;
-  constexpr int KQ = BK / 4;                  // float4 quads per tile row
-  constexpr int RPP = 256 / KQ;               // tile rows covered per loader pass (32)
-  constexpr int WAVES_M = 4 / WAVES_N;
-  constexpr int WTN = BN / WAVES_N, WTM = BM / WAVES_M;
+template <int BN, int BM, bool FLIP>
+constexpr int fused_lds_bytes() {
+  return (2 * (FLIP ? 2 : 1) * (kBK * (BN + 1) + kBK * (BM + 1)) + kMaxTaps * 4 + 24 + 8) * 4;
+}
+
+__device__ __forceinline__ double block_sum_all(double v, double* scratch) {  // 12 waves; result in thread 0
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kThreads / 64; ++i) t += scratch[i];
+  return t;
+}
+
+// INJ: the draws are READ (parity mode) instead of generated; a compile-time switch so that the producers' load phase
+// is branch-free straight-line code in both flavours (a runtime branch between two loads is a scheduling barrier).
+// LINEAR: row-major [rows][K] operands with K % 4 == 0 and 16-B aligned bases (float4 loads); any other Linear runs as a
+// 1x1 convolution over a 1x1 image, which is the same memory layout.
+template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, bool INJ>
+__global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
+  constexpr int CWM = 4 / CWN;
+  constexpr int WTN = BN / CWN, WTM = BM / CWM;
   constexpr int TN = WTN / 32, TM = WTM / 32;
-  constexpr int WS = BN + 1, XS = BM + 1;     // odd strides: conflict-free transposed ds_write_b32
+  constexpr int WS = BN + 1, XS = BM + 1;  // odd strides: the transposed ds_write_b32 scatter stays (nearly) conflict-free
   constexpr int NW = FLIP ? 2 : 1;
-  static_assert(TN >= 1 && TM >= 1 && BN % RPP == 0 && BM % 32 == 0, "tile shape");
+  constexpr int W_WORDS = kBK * WS, X_WORDS = kBK * XS, BUF_WORDS = NW * (W_WORDS + X_WORDS);
+  static_assert(TN >= 1 && TM >= 1 && BN % 32 == 0 && BM % 32 == 0 && BM <= 256, "tile shape");
   static_assert(!LINEAR || TRANS, "Linear always stores with lanes along the output features");
 
-  // one LDS array (a second __shared__ object next to staging arrays can de-pipeline the k-loop)
-  constexpr int W_WORDS = BK * WS, X_WORDS = BK * XS;
-  constexpr int TAB_WORDS = 2 * BK * 4;
-  __shared__ __attribute__((aligned(16))) float smem[NW * (W_WORDS + X_WORDS) + TAB_WORDS + 16];
-  float* const Wt0 = smem;
-  float* const Wt1 = smem + W_WORDS;                       // FLIP: sigma*eps tile
-  float* const Xt0 = smem + NW * W_WORDS;
-  float* const Xt1 = Xt0 + X_WORDS;                        // FLIP: x o s_in tile
-  int4* const ktab = reinterpret_cast<int4*>(smem + NW * (W_WORDS + X_WORDS));
-  double* const red = reinterpret_cast<double*>(smem + NW * (W_WORDS + X_WORDS) + TAB_WORDS);  // 4 doubles + flag
-  int* const flag = reinterpret_cast<int*>(red + 4);
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // ONE LDS object
+  int4* const taptab = reinterpret_cast<int4*>(smem + 2 * BUF_WORDS);
+  double* const red = reinterpret_cast<double*>(smem + 2 * BUF_WORDS + kMaxTaps * 4);
+  int* const misc = reinterpret_cast<int*>(red + 12);  // [0] active tap count, [1] last-arriver flag
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const int ptid = producer ? tid - 256 : tid;  // index inside the role: 512 producer / 256 consumer threads
   const int li = lane & 31, lh = lane >> 5;
-  const int wn = wave / WAVES_M, wm = wave % WAVES_M;
+  const int cw = wave & 3, wn = cw / CWM, wm = cw % CWM;
 
   int L = xcd_remap(blockIdx.x, a.total_blocks);
   const int mt = L % a.m_tiles;
@@ -89,10 +116,13 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdArgs a) {
   L /= a.S;
   const int nt = L % a.n_tiles;
   const int g = L / a.n_tiles;
-  const int n0 = nt * BN, m0 = mt * BM;
-  const bool kl_block = a.do_kl && mt == 0 && s == 0;
+  const int n0 = nt * BN;
+  const bool pix = a.pixel_major != 0;
+  const int tile_p = pix ? mt / a.mt_per_pixel : 0;                    // pixel-major: the tile's output pixel
+  const int m0 = pix ? (mt - tile_p * a.mt_per_pixel) * BM : mt * BM;  // first image (pixel-major) / first m
+  const int m_lim = pix ? a.B : a.M;
   const uint32_t sample = a.sample0 + (uint32_t)s;
-  const int K = a.K;
+  const int K = a.K, T = a.T, Cig = a.Cig;
 
   RngKey key_w;
   key_w.seed_lo = a.seed_lo;
@@ -103,214 +133,317 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdArgs a) {
   if (FLIP) {
     RngKey ks = key_w;
     ks.layer_tensor = layer_tensor_word(a.layer_id, 2);
-    if (!a.sign_in) skey_in = sign_stream_key(ks, sample);
+    if (!INJ) skey_in = sign_stream_key(ks, sample);
     ks.layer_tensor = layer_tensor_word(a.layer_id, 3);
-    if (!a.sign_out) skey_out = sign_stream_key(ks, sample);
+    if (!INJ) skey_out = sign_stream_key(ks, sample);
   }
 
-  // ---- loader constants -----------------------------------------------------------------------
-  const int kq = tid % KQ, lr0 = tid / KQ;  // W loader (and Linear x loader): row lr0 + 32*pass, k quad kq
-  const float* const xs = a.x + (long long)s * a.x_sample_stride;
-  const float* const eps_w_s = a.eps_w ? a.eps_w + (long long)s * a.w_elems : nullptr;
-  const float* const sin_s = (FLIP && a.sign_in) ? a.sign_in + (long long)s * a.x_elems : nullptr;
+  // ---- active taps of this tile (wave 0: ballot compaction, ascending tap order) ---------------------------------
+  if (wave == 0) {
+    int base = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+      const int t = t0 + lane;
+      bool act = false;
+      int4 e = make_int4(0, 0, 0, 0);
+      if (t < T) {
+        const int kh = t / a.KW, kw = t - kh * a.KW;
+        e = make_int4(kh * a.DH * a.W + kw * a.DW, kh * a.DH, kw * a.DW, t);
+        if (LINEAR) {
+          act = true;
+        } else if (pix) {
+          const int ho = tile_p / a.Wo, wo = tile_p - ho * a.Wo;
+          act = (unsigned)(ho * a.SH - a.PH + e.y) < (unsigned)a.H && (unsigned)(wo * a.SW - a.PW + e.z) < (unsigned)a.W;
+        } else {  // some output row/column of the full grid reaches a real input row/column through this tap
+          const int lo_h = a.PH - e.y, lo_w = a.PW - e.z;
+          const int hc = lo_h > 0 ? (lo_h + a.SH - 1) / a.SH : 0, wc = lo_w > 0 ? (lo_w + a.SW - 1) / a.SW : 0;
+          act = hc < a.Ho && hc * a.SH - lo_h < a.H && wc < a.Wo && wc * a.SW - lo_w < a.W;
+        }
+      }
+      const unsigned long long mask = __ballot(act);
+      if (act) taptab[base + __popcll(mask & ((1ull << lane) - 1ull))] = e;
+      base += __popcll(mask);
+    }
+    if (lane == 0) misc[0] = base;
+  }
+  __syncthreads();
+  const int nA = misc[0];
 
-  // conv gather: this thread owns column xm of the x tile for k rows xk0, xk0 + XKP, ...
-  constexpr int XKP = 256 / BM > 0 ? 256 / BM : 1;
-  const int xm = tid % BM, xk0 = tid / BM;
+  // ---- stage schedule: (CC channels) x (NA active taps) <= kBK rows -------------------------------------------------
+  int NA, CC;
+  if (LINEAR || nA == 1) {
+    NA = 1, CC = 32;
+  } else if (nA == 2) {
+    NA = 2, CC = 16;
+  } else if (nA <= 4) {
+    NA = nA, CC = 8;
+  } else {
+    NA = nA < 9 ? nA : 9, CC = 4;
+  }
+  while (CC > 4 && CC / 2 >= Cig) CC >>= 1;  // do not pad tiny channel counts up to a wide chunk
+  const int lcc = 31 - __clz(CC);
+  const int n_ach = (nA + NA - 1) / NA, n_cch = (Cig + CC - 1) / CC;
+  const int NS = nA ? n_ach * n_cch : 0;
+
+  // ---- producer-side constants ----------------------------------------------------------------------------------------
+  const float* const xs = a.x + (long long)s * a.x_sample_stride;
+  const float* const eps_w_s = INJ ? a.eps_w + (long long)s * a.w_elems : nullptr;
+  const float* const sin_s = (FLIP && INJ) ? a.sign_in + (long long)s * a.x_elems : nullptr;
+  constexpr int NG = kProducers / BM;  // conv gather: row groups (each thread owns one tile column for 1/NG of the rows)
+  const int xm = ptid % BM, xg = ptid / BM;
   int hi0 = 0, wi0 = 0;
-  long long xoff0 = 0;
+  int xoff0 = 0;  // element offsets fit 32 bits (the API rejects tensors of 2^30 elements or more)
   bool mvalid = false;
-  if (!LINEAR) {
-    const int m = m0 + xm;
-    mvalid = (m < a.M) && (tid < BM * XKP);
-    const int mm = mvalid ? m : 0;
-    const int b = mm / a.HoWo, p = mm - b * a.HoWo;
+  if (!LINEAR && producer) {
+    const int ml = m0 + xm;
+    mvalid = ml < m_lim;
+    int b, p;
+    if (pix) {
+      b = mvalid ? ml : 0, p = tile_p;
+    } else {
+      const int mm = mvalid ? ml : 0;
+      b = mm / a.HoWo, p = mm - b * a.HoWo;
+    }
     const int ho = p / a.Wo, wo = p - ho * a.Wo;
     hi0 = ho * a.SH - a.PH;
     wi0 = wo * a.SW - a.PW;
-    xoff0 = ((long long)b * a.Ci + (long long)g * a.Cig) * a.H * a.W + (long long)hi0 * a.W + wi0;
+    xoff0 = (b * a.Ci + g * Cig) * a.HW + hi0 * a.W + wi0;
   }
+  const bool quad_rng = (Cig & 3) == 0;  // 4 consecutive channels of one tap are exactly one Philox block
 
-  auto fill_ktab = [&](int buf, int k0) {
-    if (!LINEAR && tid < BK) {
-      const int k = k0 + tid;
-      int4 e = make_int4(0, 1 << 24, 1 << 24, 0);  // fails the bounds test
-      if (k < K) {
-        const int taps = a.KH * a.KW;
-        const int ci = k / taps, r = k - ci * taps;
-        const int kh = r / a.KW, kw = r - kh * a.KW;
-        e.x = ci * a.H * a.W + kh * a.DH * a.W + kw * a.DW;
-        e.y = kh * a.DH;
-        e.z = kw * a.DW;
+  // One stage of producer work. All global loads of the stage (weights, then activations) are issued before any of
+  // them is consumed, unconditionally on clamped offsets (a load under a per-lane condition, or a runtime branch
+  // between two loads, makes hipcc wait for each one alone), and the Philox/Box-Muller arithmetic -- which depends
+  // on no load -- runs while they are in flight. LCC = log2(channels per stage) is a compile-time constant so that
+  // the gather is a static (tap, channel) nest: per tap one table read and one bounds test, per element ~5 instructions.
+  auto produce = [&](auto LCCc, int st, float* buf) {
+    constexpr int LCC = decltype(LCCc)::value, CCs = 1 << LCC;
+    float* const Wt0 = buf;
+    float* const Wt1 = buf + W_WORDS;
+    float* const Xt0 = buf + NW * W_WORDS;
+    float* const Xt1 = Xt0 + X_WORDS;
+    const int cch = st / n_ach, ach = st - cch * n_ach;
+    const int a0 = ach * NA, c0 = cch * CCs;
+    const int na_s = (nA - a0) < NA ? (nA - a0) : NA;
+    // -------- weights: unit = (row r, channel quad cq, active tap ai) -> 4 sampled weights -------------------------
+    constexpr int UMAX = (BN * 9 + kProducers - 1) / kProducers;  // a stage holds at most 9 quads per row
+    constexpr int ncq = CCs >> 2, lncq = LCC - 2;
+    const int nunits = BN * ncq * na_s;
+    const uint32_t inv_na = (uint32_t)((0x100000000ull + (unsigned)na_s - 1) / (unsigned)na_s);
+    float mu[UMAX][4], rho[UMAX][4], ep[UMAX][4];
+    int urow[UMAX], ukc[UMAX];
+    uint32_t ue0[UMAX];
+    unsigned uval[UMAX];  // bit j: element j exists; bit 4: row exists; bit 5: no unit at all
+#pragma unroll
+    for (int i = 0; i < UMAX; ++i) {
+      const int u = ptid + kProducers * i;
+      const int uu = u < nunits ? u : 0;
+      const int tq = na_s == 1 ? uu : (int)__umulhi((uint32_t)uu, inv_na);  // uu / na_s (exact for uu < 2^16; 2^32/1 does not fit)
+      const int ai = uu - tq * na_s;
+      const int cq = tq & (ncq - 1), r = tq >> lncq;
+      const int tap = LINEAR ? 0 : taptab[a0 + ai].w;
+      const int co_g = n0 + r, ci = c0 + 4 * cq;
+      const bool rv = (u < nunits) && (co_g < a.Cog);
+      const uint32_t co = (uint32_t)(g * a.Cog + co_g);
+      const uint32_t base = co * (uint32_t)K + (uint32_t)(ci * T + tap);  // natural [co][ci][tap] offset of channel ci
+      ue0[i] = (co * (uint32_t)T + (uint32_t)tap) * (uint32_t)Cig + (uint32_t)ci;  // tap-major draw index of channel ci
+      urow[i] = r;
+      ukc[i] = (ai << LCC) + 4 * cq;
+      unsigned val = rv ? 16u : 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ep[i][j] = 0.f;
+        if (rv && (ci + j < Cig)) val |= 1u << j;
       }
-      ktab[buf * BK + tid] = e;
-    }
-  };
-
-  f32x16 acc[NW][TN][TM];
-#pragma unroll
-  for (int w = 0; w < NW; ++w)
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[w][i][j][r] = 0.f;
-
-  double kl_acc = 0.0;
-  fill_ktab(0, 0);
-  __syncthreads();
-
-  int buf = 0;
-  for (int k0 = 0; k0 < K; k0 += BK, buf ^= 1) {
-    // ---------------- W tile: (mu, rho) [+eps] -> registers -> sampled weights -> LDS (transposed) ------
-#pragma unroll
-    for (int p = 0; p < BN / RPP; ++p) {
-      const int r = lr0 + p * RPP;
-      const int co_g = n0 + r;
-      const int k = k0 + 4 * kq;
-      const bool rv = co_g < a.Cog;
-      const long long widx = ((long long)g * a.Cog + co_g) * K + k;
-      float mu[4] = {0.f, 0.f, 0.f, 0.f}, rho[4] = {0.f, 0.f, 0.f, 0.f}, ep[4] = {0.f, 0.f, 0.f, 0.f};
-      float pm[4] = {0.f, 0.f, 0.f, 0.f}, ps[4] = {1.f, 1.f, 1.f, 1.f};
-      bool ev[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ev[j] = rv && (k + j < K);
-      if (a.w_vec) {
-        if (ev[0]) {  // K % 4 == 0: the quad is all-in or all-out
-          const float4 m4 = *reinterpret_cast<const float4*>(a.mu_w + widx);
-          const float4 r4 = *reinterpret_cast<const float4*>(a.rho_w + widx);
-          mu[0] = m4.x, mu[1] = m4.y, mu[2] = m4.z, mu[3] = m4.w;
-          rho[0] = r4.x, rho[1] = r4.y, rho[2] = r4.z, rho[3] = r4.w;
-          if (eps_w_s) {
-            const float4 e4 = *reinterpret_cast<const float4*>(eps_w_s + widx);
-            ep[0] = e4.x, ep[1] = e4.y, ep[2] = e4.z, ep[3] = e4.w;
-          } else {
-            philox_normal4(key_w, sample, (uint32_t)(widx >> 2), ep);
-          }
-          if (kl_block) {
-            const float4 a4 = *reinterpret_cast<const float4*>(a.pmu_w + widx);
-            const float4 b4 = *reinterpret_cast<const float4*>(a.psig_w + widx);
-            pm[0] = a4.x, pm[1] = a4.y, pm[2] = a4.z, pm[3] = a4.w;
-            ps[0] = b4.x, ps[1] = b4.y, ps[2] = b4.z, ps[3] = b4.w;
-          }
+      if (u >= nunits) val = 32u;
+      uval[i] = val;
+      if constexpr (LINEAR) {  // the quad is contiguous and all-in or all-out
+        const bool in = (val & 1u) != 0;
+        const uint32_t sb = in ? base : 0u;
+        const float4 m4 = *reinterpret_cast<const float4*>(a.mu_w + sb);
+        const float4 r4 = *reinterpret_cast<const float4*>(a.rho_w + sb);
+        mu[i][0] = in ? m4.x : 0.f, mu[i][1] = in ? m4.y : 0.f, mu[i][2] = in ? m4.z : 0.f, mu[i][3] = in ? m4.w : 0.f;
+        rho[i][0] = in ? r4.x : 0.f, rho[i][1] = in ? r4.y : 0.f, rho[i][2] = in ? r4.z : 0.f, rho[i][3] = in ? r4.w : 0.f;
+        if constexpr (INJ) {
+          const float4 e4 = *reinterpret_cast<const float4*>(eps_w_s + sb);
+          ep[i][0] = in ? e4.x : 0.f, ep[i][1] = in ? e4.y : 0.f, ep[i][2] = in ? e4.z : 0.f, ep[i][3] = in ? e4.w : 0.f;
         }
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (ev[j]) {
-            mu[j] = a.mu_w[widx + j];
-            rho[j] = a.rho_w[widx + j];
-            if (eps_w_s) {
-              ep[j] = eps_w_s[widx + j];
-            } else {
-              float z[4];
-              philox_normal4(key_w, sample, (uint32_t)((widx + j) >> 2), z);
-              const int sel = (int)((widx + j) & 3);
-              ep[j] = sel == 0 ? z[0] : sel == 1 ? z[1] : sel == 2 ? z[2] : z[3];
-            }
-            if (kl_block) {
-              pm[j] = a.pmu_w[widx + j];
-              ps[j] = a.psig_w[widx + j];
-            }
+          const bool in = (val >> j) & 1u;
+          const uint32_t sb = in ? base + (uint32_t)(j * T) : 0u;
+          const float m1 = a.mu_w[sb], r1 = a.rho_w[sb];
+          mu[i][j] = in ? m1 : 0.f;
+          rho[i][j] = in ? r1 : 0.f;
+          if constexpr (INJ) {
+            const float e1 = eps_w_s[sb];
+            ep[i][j] = in ? e1 : 0.f;
           }
         }
       }
-      float kl4 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float sg = softplus(rho[j]);
-        const float dl = __fmul_rn(sg, ep[j]);
-        float w0, w1 = 0.f;
-        if (FLIP) {
-          w0 = mu[j];
-          w1 = dl;
-        } else {
-          w0 = __fadd_rn(mu[j], dl);
-        }
-        Wt0[(4 * kq + j) * WS + r] = ev[j] ? w0 : 0.f;
-        if (FLIP) Wt1[(4 * kq + j) * WS + r] = ev[j] ? w1 : 0.f;
-        if (kl_block) kl4 += ev[j] ? kl_term(mu[j], sg, pm[j], ps[j]) : 0.f;
-      }
-      if (kl_block) kl_acc += (double)kl4;
     }
-
-    // ---------------- x tile -----------------------------------------------------------------------------
-    if (LINEAR) {
+    // -------- activations: loads --------------------------------------------------------------------------------------------
+    constexpr bool FASTX = !LINEAR && (NG <= 4);                   // static (tap, channel) nest; NG <= 4 <= CC
+    constexpr int CPT = FASTX ? CCs / NG : 1;                      // channels per (thread, tap)
+    constexpr int TPS = FASTX ? kBK / CCs : 1;                     // tap slots of a stage
+    constexpr int RP = kProducers / 8;                             // Linear: tile rows per pass
+    constexpr int NXR = LINEAR ? ((BM + RP - 1) / RP) * 4 : (FASTX ? TPS * CPT : (kBK + NG - 1) / NG);
+    float xv[NXR], xs_[FLIP ? NXR : 1];
+    uint32_t xo[FLIP ? NXR : 1];
+    if constexpr (LINEAR) {
+      const int kq = ptid & 7, mr = ptid >> 3;
 #pragma unroll
-      for (int p = 0; p < BM / RPP; ++p) {
-        const int r = lr0 + p * RPP;
-        const int m = m0 + r;
-        const int k = k0 + 4 * kq;
-        const long long xo = (long long)m * K + k;
-        float v[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {1.f, 1.f, 1.f, 1.f};
-        const bool rv = m < a.M;
-        if (a.x_vec) {
-          if (rv && k < K) {
-            const float4 x4 = *reinterpret_cast<const float4*>(xs + xo);
-            v[0] = x4.x, v[1] = x4.y, v[2] = x4.z, v[3] = x4.w;
-            if (FLIP && sin_s) {
-              const float4 s4 = *reinterpret_cast<const float4*>(sin_s + xo);
-              sg[0] = s4.x, sg[1] = s4.y, sg[2] = s4.z, sg[3] = s4.w;
-            }
+      for (int p = 0; p < (BM + RP - 1) / RP; ++p) {
+        const int rl = mr + p * RP;
+        const int m = m0 + rl, k = c0 + 4 * kq;
+        const uint32_t off = (uint32_t)m * (uint32_t)K + (uint32_t)k;
+        const bool in = rl < BM && m < a.M && k < K;
+        const uint32_t so = in ? off : 0u;
+        const float4 x4 = *reinterpret_cast<const float4*>(xs + so);
+        xv[4 * p] = in ? x4.x : 0.f, xv[4 * p + 1] = in ? x4.y : 0.f, xv[4 * p + 2] = in ? x4.z : 0.f, xv[4 * p + 3] = in ? x4.w : 0.f;
+        if constexpr (FLIP) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xo[4 * p + j] = off + j;
+          if constexpr (INJ) {
+            const float4 s4 = *reinterpret_cast<const float4*>(sin_s + so);
+            xs_[4 * p] = s4.x, xs_[4 * p + 1] = s4.y, xs_[4 * p + 2] = s4.z, xs_[4 * p + 3] = s4.w;
           }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (rv && k + j < K) {
-              v[j] = xs[xo + j];
-              if (FLIP && sin_s) sg[j] = sin_s[xo + j];
-            }
         }
+      }
+    } else if constexpr (FASTX) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          Xt0[(4 * kq + j) * XS + r] = v[j];
-          if (FLIP) {
-            const float sj = sin_s ? sg[j] : hash_sign(skey_in, (uint32_t)(xo + j));
-            Xt1[(4 * kq + j) * XS + r] = __fmul_rn(v[j], sj);
+      for (int t = 0; t < TPS; ++t) {
+        const int4 e = taptab[a0 + (t < na_s ? t : 0)];
+        const bool okt = mvalid && t < na_s && (unsigned)(hi0 + e.y) < (unsigned)a.H && (unsigned)(wi0 + e.z) < (unsigned)a.W;
+        const int ci0 = c0 + xg;
+        const int base = xoff0 + e.x + ci0 * a.HW;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+          const bool ok = okt && (ci0 + c * NG < Cig);
+          const uint32_t off = ok ? (uint32_t)(base + c * NG * a.HW) : 0u;
+          const float x1 = xs[off];
+          xv[t * CPT + c] = ok ? x1 : 0.f;
+          if constexpr (FLIP) {
+            xo[t * CPT + c] = off;
+            if constexpr (INJ) xs_[t * CPT + c] = sin_s[off];
           }
         }
       }
     } else {
-      float v[BK / XKP], sg[BK / XKP];
-      long long xo[BK / XKP];
+      const int KC = na_s << LCC;
 #pragma unroll
-      for (int p = 0; p < BK / XKP; ++p) {
-        const int kk = xk0 + p * XKP;
-        const int4 e = ktab[buf * BK + kk];
-        const bool ok = mvalid && (unsigned)(hi0 + e.y) < (unsigned)a.H && (unsigned)(wi0 + e.z) < (unsigned)a.W;
-        xo[p] = xoff0 + e.x;
-        v[p] = ok ? xs[xo[p]] : 0.f;
-        if (FLIP) sg[p] = (ok && sin_s) ? sin_s[xo[p]] : 1.f;
+      for (int q = 0; q < NXR; ++q) {
+        const int kc = xg + q * NG;
+        const int4 e = taptab[a0 + (kc < KC ? (kc >> LCC) : 0)];
+        const int ci = c0 + (kc & (CCs - 1));
+        const bool ok = mvalid && kc < KC && ci < Cig && (unsigned)(hi0 + e.y) < (unsigned)a.H && (unsigned)(wi0 + e.z) < (unsigned)a.W;
+        const uint32_t off = ok ? (uint32_t)(xoff0 + ci * a.HW + e.x) : 0u;
+        const float x1 = xs[off];
+        xv[q] = ok ? x1 : 0.f;
+        if constexpr (FLIP) {
+          xo[q] = off;
+          if constexpr (INJ) xs_[q] = sin_s[off];
+        }
       }
+    }
+    // -------- draws (independent of every load above) ----------------------------------------------------------------------
+    if constexpr (!INJ) {
+      if (quad_rng) {
 #pragma unroll
-      for (int p = 0; p < BK / XKP; ++p) {
-        const int kk = xk0 + p * XKP;
-        if (tid < BM * XKP) {
-          Xt0[kk * XS + xm] = v[p];
-          if (FLIP) {
-            const float sj = sin_s ? sg[p] : hash_sign(skey_in, (uint32_t)xo[p]);
-            Xt1[kk * XS + xm] = __fmul_rn(v[p], sj);
+        for (int i = 0; i < UMAX; ++i)
+          if (uval[i] & 16u) philox_normal4(key_w, sample, ue0[i] >> 2, ep[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < UMAX; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (uval[i] & (1u << j)) {
+              float z[4];
+              philox_normal4(key_w, sample, (ue0[i] + j) >> 2, z);
+              const int sel = (int)((ue0[i] + j) & 3);
+              ep[i][j] = sel == 0 ? z[0] : sel == 1 ? z[1] : sel == 2 ? z[2] : z[3];
+            }
+      }
+    }
+    // -------- sampled weights -> LDS (transposed) ---------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < UMAX; ++i) {
+      if (!(uval[i] & 32u)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ev = (uval[i] >> j) & 1u;
+          const float dl = __fmul_rn(softplus(rho[i][j]), ep[i][j]);
+          const float w0 = FLIP ? mu[i][j] : __fadd_rn(mu[i][j], dl);
+          Wt0[(ukc[i] + j) * WS + urow[i]] = ev ? w0 : 0.f;
+          if (FLIP) Wt1[(ukc[i] + j) * WS + urow[i]] = ev ? dl : 0.f;
+        }
+      }
+    }
+    // -------- activations -> LDS -------------------------------------------------------------------------------------------------
+    if constexpr (LINEAR) {
+      const int kq = ptid & 7, mr = ptid >> 3;
+#pragma unroll
+      for (int p = 0; p < (BM + RP - 1) / RP; ++p) {
+        const int rl = mr + p * RP;
+        if (rl < BM) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int idx = (4 * kq + j) * XS + rl;
+            Xt0[idx] = xv[4 * p + j];
+            if (FLIP) Xt1[idx] = __fmul_rn(xv[4 * p + j], INJ ? xs_[4 * p + j] : hash_sign(skey_in, xo[4 * p + j]));
           }
         }
       }
-      fill_ktab(buf ^ 1, k0 + BK);
-    }
-    __syncthreads();
-
-    // ---------------- contraction on the fp32 matrix cores ----------------------------------------------
+    } else if constexpr (FASTX) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
+      for (int t = 0; t < TPS; ++t)
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {  // rows past the stage's last tap are written too (never read; inside the buffer)
+          const int idx = ((t << LCC) + xg + c * NG) * XS + xm;
+          Xt0[idx] = xv[t * CPT + c];
+          if (FLIP) Xt1[idx] = __fmul_rn(xv[t * CPT + c], INJ ? xs_[t * CPT + c] : hash_sign(skey_in, xo[t * CPT + c]));
+        }
+    } else {
+      const int KC = na_s << LCC;
+#pragma unroll
+      for (int q = 0; q < NXR; ++q) {
+        const int kc = xg + q * NG;
+        if (kc < KC) {
+          Xt0[kc * XS + xm] = xv[q];
+          if (FLIP) Xt1[kc * XS + xm] = __fmul_rn(xv[q], INJ ? xs_[q] : hash_sign(skey_in, xo[q]));
+        }
+      }
+    }
+  };
+  auto produce_stage = [&](int st, float* buf) {
+    switch (lcc) {
+      case 2: produce(std::integral_constant<int, 2>{}, st, buf); break;
+      case 3: produce(std::integral_constant<int, 3>{}, st, buf); break;
+      case 4: produce(std::integral_constant<int, 4>{}, st, buf); break;
+      default: produce(std::integral_constant<int, 5>{}, st, buf); break;
+    }
+  };
+
+  auto consume = [&](f32x16 (&acc)[NW][TN][TM], int st, const float* buf) {
+    const float* const Wt0 = buf + wn * WTN + li;
+    const float* const Wt1 = Wt0 + W_WORDS;
+    const float* const Xt0 = buf + NW * W_WORDS + wm * WTM + li;
+    const float* const Xt1 = Xt0 + X_WORDS;
+    const int cch = st / n_ach, ach = st - cch * n_ach;
+    const int na_s = (nA - ach * NA) < NA ? (nA - ach * NA) : NA;
+    const int KC = na_s << lcc;  // even (CC >= 4)
+#pragma unroll 2
+    for (int kk = 0; kk < KC; kk += 2) {
       float af[NW][TN], bf[NW][TM];
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
-        af[0][i] = Wt0[(kk + lh) * WS + wn * WTN + i * 32 + li];
-        if (FLIP) af[NW - 1][i] = Wt1[(kk + lh) * WS + wn * WTN + i * 32 + li];
+        af[0][i] = Wt0[(kk + lh) * WS + i * 32];
+        if (FLIP) af[NW - 1][i] = Wt1[(kk + lh) * WS + i * 32];
       }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        bf[0][j] = Xt0[(kk + lh) * XS + wm * WTM + j * 32 + li];
-        if (FLIP) bf[NW - 1][j] = Xt1[(kk + lh) * XS + wm * WTM + j * 32 + li];
+        bf[0][j] = Xt0[(kk + lh) * XS + j * 32];
+        if (FLIP) bf[NW - 1][j] = Xt1[(kk + lh) * XS + j * 32];
       }
 #pragma unroll
       for (int w = 0; w < NW; ++w)
@@ -321,109 +454,177 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdArgs a) {
             acc[w][i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[w][j], af[w][i], acc[w][i][j], 0, 0, 0)
                                  : __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i], bf[w][j], acc[w][i][j], 0, 0, 0);
     }
-    __syncthreads();
-  }
+  };
 
-  // ---------------- epilogue: bias draw, Flipout sign_out, store ------------------------------------------
-  float* const bias0 = Wt0;        // reparam: mu_b + sigma_b*eps_b ; flipout: mu_b
-  float* const bias1 = Wt0 + BN;   // flipout: sigma_b*eps_b
-  if (tid < BN) {
-    float b0 = 0.f, b1 = 0.f;
-    const int co_g = n0 + tid;
-    if (a.mu_b && co_g < a.Cog) {
-      const int co = g * a.Cog + co_g;
-      float e;
-      if (a.eps_b) {
-        e = a.eps_b[(long long)s * a.Co + co];
-      } else {
-        RngKey kb = key_w;
-        kb.layer_tensor = layer_tensor_word(a.layer_id, 1);
-        float z[4];
-        philox_normal4(kb, sample, (uint32_t)(co >> 2), z);
-        const int sel = co & 3;
-        e = sel == 0 ? z[0] : sel == 1 ? z[1] : sel == 2 ? z[2] : z[3];
-      }
-      const float dl = __fmul_rn(softplus(a.rho_b[co]), e);
-      if (FLIP) {
-        b0 = a.mu_b[co];
+  float* const buf0 = smem;
+  float* const buf1 = smem + BUF_WORDS;
+  float* const bias0 = smem;       // reparam: mu_b + sigma_b*eps_b ; flipout: mu_b   (aliases stage memory after the last barrier)
+  float* const bias1 = smem + BN;  // flipout: sigma_b*eps_b
+  float* const osc = smem + 2 * BN;  // output stage: per-channel scale (1 when absent)
+  float* const osh = smem + 3 * BN;  //               per-channel shift (0 when absent)
+  double kl_acc = 0.0;
+  const bool kl_block = a.do_kl && (int)blockIdx.x < a.kl_slices;
+
+  // The two roles are separate control-flow arms with the same number of workgroup barriers, so the accumulator
+  // registers live only in the consumer arm and the producer arm gets the whole register budget for loads in flight.
+  if (producer) {
+    for (int st = 0; st <= NS; ++st) {  // NS + 1 barriers, like the consumer arm
+      if (st < NS) produce_stage(st, (st & 1) ? buf1 : buf0);
+      __syncthreads();
+    }
+    // bias draw for this workgroup's output channels
+    if (ptid < BN) {
+      float b0 = 0.f, b1 = 0.f;
+      const int co_g = n0 + ptid;
+      if (a.mu_b && co_g < a.Cog) {
+        const int co = g * a.Cog + co_g;
+        float e;
+        if (INJ) {
+          e = a.eps_b[(long long)s * a.Co + co];
+        } else {
+          RngKey kb = key_w;
+          kb.layer_tensor = layer_tensor_word(a.layer_id, 1);
+          float z[4];
+          philox_normal4(kb, sample, (uint32_t)(co >> 2), z);
+          const int sel = co & 3;
+          e = sel == 0 ? z[0] : sel == 1 ? z[1] : sel == 2 ? z[2] : z[3];
+        }
+        const float dl = __fmul_rn(softplus(a.rho_b[co]), e);
+        b0 = FLIP ? a.mu_b[co] : __fadd_rn(a.mu_b[co], dl);
         b1 = dl;
-      } else {
-        b0 = __fadd_rn(a.mu_b[co], dl);
       }
+      bias0[ptid] = b0;
+      if (FLIP) bias1[ptid] = b1;
+      const bool cv = a.ep_scale && co_g < a.Cog;
+      const int cs = cv ? g * a.Cog + co_g : 0;
+      const float sc = a.ep_scale ? a.ep_scale[cs] : 1.f, sh = a.ep_shift ? a.ep_shift[cs] : 0.f;
+      osc[ptid] = cv ? sc : 1.f;
+      osh[ptid] = cv ? sh : 0.f;
     }
-    bias0[tid] = b0;
-    if (FLIP) bias1[tid] = b1;
-  }
-  __syncthreads();
-
-  float* const out_s = a.out + (long long)s * a.out_elems;
-  const float* const sout_s = (FLIP && a.sign_out) ? a.sign_out + (long long)s * a.out_elems : nullptr;
-  const float* const res_s = a.ep_res ? a.ep_res + (long long)s * a.ep_res_stride : nullptr;
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    int b_col = 0, p_col = 0;
-    if (!TRANS) {  // lanes run along m: decode this lane's column once
-      const int m = m0 + wm * WTM + j * 32 + li;
-      b_col = m / a.HoWo;
-      p_col = m - b_col * a.HoWo;
-    }
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        int co_l, m;
-        long long oidx;
-        if (TRANS) {  // D[m][co]: lanes along co, HoWo == 1
-          co_l = wn * WTN + i * 32 + li;
-          m = m0 + wm * WTM + j * 32 + row;
-          oidx = (long long)m * a.Co + (long long)g * a.Cog + n0 + co_l;
-        } else {      // D[co][m]: lanes along the spatial index (NCHW-contiguous)
-          co_l = wn * WTN + i * 32 + row;
-          m = m0 + wm * WTM + j * 32 + li;
-          oidx = ((long long)b_col * a.Co + (long long)g * a.Cog + n0 + co_l) * a.HoWo + p_col;
-        }
-        if (n0 + co_l < a.Cog && m < a.M) {
-          float v = __fadd_rn(acc[0][i][j][r], bias0[co_l]);
-          if (FLIP) {
-            const float so = sout_s ? sout_s[oidx] : hash_sign(skey_out, (uint32_t)oidx);
-            v = __fadd_rn(v, __fmul_rn(__fadd_rn(acc[NW - 1][i][j][r], bias1[co_l]), so));
-          }
-          if (a.ep_scale) {
-            const int co = g * a.Cog + n0 + co_l;
-            v = __fadd_rn(__fmul_rn(v, a.ep_scale[co]), a.ep_shift[co]);
-          }
-          if (res_s) v = __fadd_rn(v, res_s[oidx]);
-          if (a.ep_relu) v = fmaxf(v, 0.f);
-          out_s[oidx] = v;
+    __syncthreads();
+  } else {
+    // consumers sweep this workgroup's slice of the weights for KL while the producers fill stage 0
+    if (kl_block) {
+      long long chunk = (a.w_elems + a.kl_slices - 1) / a.kl_slices;
+      chunk = (chunk + 3) & ~3ll;
+      const long long lo = (long long)blockIdx.x * chunk;
+      const long long hi = (lo + chunk < a.w_elems) ? lo + chunk : a.w_elems;
+      const bool v4 = ((((uintptr_t)a.mu_w | (uintptr_t)a.rho_w | (uintptr_t)a.pmu_w | (uintptr_t)a.psig_w) & 15u) == 0);
+      long long i = lo + 4ll * ptid;
+      if (v4) {
+        for (; i + 3 < hi; i += 1024) {
+          const float4 m4 = *reinterpret_cast<const float4*>(a.mu_w + i), r4 = *reinterpret_cast<const float4*>(a.rho_w + i);
+          const float4 p4 = *reinterpret_cast<const float4*>(a.pmu_w + i), q4 = *reinterpret_cast<const float4*>(a.psig_w + i);
+          const float t0 = kl_term(m4.x, softplus(r4.x), p4.x, q4.x) + kl_term(m4.y, softplus(r4.y), p4.y, q4.y);
+          const float t1 = kl_term(m4.z, softplus(r4.z), p4.z, q4.z) + kl_term(m4.w, softplus(r4.w), p4.w, q4.w);
+          kl_acc += (double)t0 + (double)t1;
         }
       }
+      for (; i < hi; i += 1024)  // tail quad / unaligned bases
+        for (int j = 0; j < 4; ++j)
+          if (i + j < hi) kl_acc += (double)kl_term(a.mu_w[i + j], softplus(a.rho_w[i + j]), a.pmu_w[i + j], a.psig_w[i + j]);
+    }
+    __syncthreads();
+
+    f32x16 acc[NW][TN][TM];
+  #pragma unroll
+    for (int w = 0; w < NW; ++w)
+  #pragma unroll
+      for (int i = 0; i < TN; ++i)
+  #pragma unroll
+        for (int j = 0; j < TM; ++j)
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) acc[w][i][j][r] = 0.f;
+    for (int st = 0; st < NS; ++st) {  // one barrier per stage
+      consume(acc, st, (st & 1) ? buf1 : buf0);
+      __syncthreads();
+    }
+    __syncthreads();  // the producers have staged the bias
+
+    // output stage + store
+    float* const out_s = a.out + (long long)s * a.out_elems;
+    const float* const sout_s = (FLIP && INJ) ? a.sign_out + (long long)s * a.out_elems : nullptr;
+    const float* const res_s = a.ep_res ? a.ep_res + (long long)s * a.ep_res_stride : nullptr;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      int b_col = 0, p_col = tile_p;
+      if (!TRANS) {  // lanes run along m: decode this lane's column once
+        const int ml = m0 + wm * WTM + j * 32 + li;
+        if (pix) {
+          b_col = ml;
+        } else {
+          b_col = ml / a.HoWo;
+          p_col = ml - b_col * a.HoWo;
+        }
+      }
+      const bool relu = a.ep_relu != 0;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        // All reads of the tile (residual, injected signs) are issued before the first dependent instruction:
+        // unconditional loads on clamped indices, selected afterwards (same reason as in produce()).
+        uint32_t oi[16];
+        bool okv[16];
+        int col[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          int co_l, ml;
+          if (TRANS) {  // D[m][co]: lanes along co (HoWo == 1, or pixel-major tiles)
+            co_l = wn * WTN + i * 32 + li;
+            ml = m0 + wm * WTM + j * 32 + row;
+            oi[r] = (uint32_t)((ml * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + tile_p);
+          } else {      // D[co][m]: lanes along the spatial index (NCHW-contiguous)
+            co_l = wn * WTN + i * 32 + row;
+            ml = m0 + wm * WTM + j * 32 + li;
+            oi[r] = (uint32_t)((b_col * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + p_col);
+          }
+          okv[r] = n0 + co_l < a.Cog && ml < m_lim;
+          col[r] = co_l;
+          if (!okv[r]) oi[r] = 0u;
+        }
+        float rs[16], so[FLIP ? 16 : 1];
+        if (res_s) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rs[r] = res_s[oi[r]];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rs[r] = 0.f;
+        }
+        if constexpr (FLIP) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) so[r] = INJ ? sout_s[oi[r]] : hash_sign(skey_out, oi[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = __fadd_rn(acc[0][i][j][r], bias0[col[r]]);
+          if constexpr (FLIP) v = __fadd_rn(v, __fmul_rn(__fadd_rn(acc[NW - 1][i][j][r], bias1[col[r]]), so[r]));
+          v = __fadd_rn(__fmul_rn(v, osc[col[r]]), osh[col[r]]);
+          v = __fadd_rn(v, rs[r]);
+          v = (relu && v < 0.f) ? 0.f : v;  // a select, so NaN propagates like torch's relu
+          if (okv[r]) out_s[oi[r]] = v;
+        }
+      }
     }
   }
 
-  // ---------------- KL finish ------------------------------------------------------------------------------
+  // ---- KL finish ------------------------------------------------------------------------------------------------------------
   if (!kl_block) return;
-  const double bsum = block_sum_256(kl_acc, red);
-  if (tid == 0) *flag = publish_and_ticket(a.slots, a.counter, g * a.n_tiles + nt, bsum, (unsigned)(a.G * a.n_tiles)) ? 1 : 0;
+  const double bsum = block_sum_all(kl_acc, red);
+  if (tid == 0) misc[1] = publish_and_ticket(a.slots, a.counter, (int)blockIdx.x, bsum, (unsigned)a.kl_slices) ? 1 : 0;
   __syncthreads();
-  if (!*flag) return;
+  if (!misc[1]) return;
   double bacc = 0.0;
   if (a.mu_b)
-    for (int c = tid; c < a.Co; c += 256) bacc += (double)kl_term(a.mu_b[c], softplus(a.rho_b[c]), a.pmu_b[c], a.psig_b[c]);
-  __syncthreads();
-  const double bias_sum = block_sum_256(bacc, red);
+    for (int c = tid; c < a.Co; c += kThreads) bacc += (double)kl_term(a.mu_b[c], softplus(a.rho_b[c]), a.pmu_b[c], a.psig_b[c]);
+  const double bias_sum = block_sum_all(bacc, red);
   if (tid == 0) {
     double wsum = 0.0;
-    const int nslots = a.G * a.n_tiles;
-    for (int i = 0; i < nslots; ++i) wsum += __hip_atomic_load(&a.slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < a.kl_slices; ++i) wsum += __hip_atomic_load(&a.slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float kl = (float)(wsum / (double)a.w_elems);
     if (a.mu_b) kl += (float)(bias_sum / (double)a.Co);
     a.kl_out[0] = kl;
     __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-
-// host side ------------------------------------------------------------------------------------------------
-
 
 }  // namespace bt

@@ -13,17 +13,26 @@ int set_error(int code, const char* msg) {
   return code;
 }
 
-// out[s][i], i in [0, n): the exact eps stream the fused kernels consume. One thread per 4 elements.
-__global__ __launch_bounds__(256) void rng_normal_fill_kernel(RngKey k, const uint32_t* call_base, uint32_t sample0, long long n, float* __restrict__ out) {
+// out[s][r][c][t] (natural order) <- the tap-major eps stream the fused kernels consume (bt_hip.h).
+// One thread per Philox block: 4 consecutive values of e = (r*taps + t)*inner + c.
+__global__ __launch_bounds__(256) void rng_normal_fill_kernel(RngKey k, const uint32_t* call_base, uint32_t sample0, long long rows,
+                                                              long long inner, long long taps, float* __restrict__ out) {
   if (call_base) k.call += *call_base;
+  const long long n = rows * inner * taps;
   const long long nq = (n + 3) >> 2;
   const int s = blockIdx.y;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long long)gridDim.x * 256) {
     float z[4];
     philox_normal4(k, sample0 + s, (uint32_t)q, z);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (q * 4 + j < n) out[(long long)s * n + q * 4 + j] = z[j];
+    for (int j = 0; j < 4; ++j) {
+      const long long e = q * 4 + j;
+      if (e < n) {
+        const long long c = e % inner, rt = e / inner;
+        const long long t = rt % taps, r = rt / taps;
+        out[(long long)s * n + (r * inner + c) * taps + t] = z[j];
+      }
+    }
   }
 }
 
@@ -89,13 +98,18 @@ __global__ __launch_bounds__(256) void mc_epilogue_kernel(int S, int B, int C, c
 extern "C" int bt_version(void) { return BT_VERSION; }
 extern "C" const char* bt_last_error_string(void) { return bt::g_err; }
 
-extern "C" int bt_rng_normal_fill(const bt_rng* rng, uint32_t tensor_id, int32_t S, int64_t n, float* out, bt_stream_t stream) {
+extern "C" int bt_rng_normal_fill(const bt_rng* rng, uint32_t tensor_id, int32_t S, int64_t rows, int64_t inner, int64_t taps, float* out,
+                                  bt_stream_t stream) {
   using namespace bt;
-  if (!rng || !out || S <= 0 || n <= 0 || tensor_id > 3 || S > 65535) return set_error(BT_ERR_BAD_ARG, "bt_rng_normal_fill: bad argument");
+  if (!rng || !out || S <= 0 || rows <= 0 || inner <= 0 || taps <= 0 || tensor_id > 3 || S > 65535)
+    return set_error(BT_ERR_BAD_ARG, "bt_rng_normal_fill: bad argument");
+  const long long n = (long long)rows * inner * taps;
+  if (n > (1ll << 34)) return set_error(BT_ERR_UNSUPPORTED, "bt_rng_normal_fill: tensor too large");
   const long long nq = (n + 3) >> 2;
   int gx = (int)((nq + 255) / 256);
   if (gx > 2048) gx = 2048;
-  hipLaunchKernelGGL(rng_normal_fill_kernel, dim3(gx, S), dim3(256), 0, (hipStream_t)stream, make_key(*rng, tensor_id), rng->call_base_dev, rng->sample0, (long long)n, out);
+  hipLaunchKernelGGL(rng_normal_fill_kernel, dim3(gx, S), dim3(256), 0, (hipStream_t)stream, make_key(*rng, tensor_id), rng->call_base_dev,
+                     rng->sample0, (long long)rows, (long long)inner, (long long)taps, out);
   return check_launch("bt_rng_normal_fill");
 }
 

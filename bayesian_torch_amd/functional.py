@@ -87,12 +87,33 @@ def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=Non
     return out, kl
 
 
-def rng_fill(kind, seed, call, layer_id, sample0, tensor_id, S, n, device, call_base=None):
-    """Materialise the on-chip stream: kind 'normal' (eps) or 'sign'. -> [S, n]"""
-    R = _lib.bt_rng(int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(call_base), int(call) & 0xFFFFFFFF, int(layer_id), int(sample0), 0)
-    out = torch.empty((S, n), dtype=torch.float32, device=device)
-    fn = _lib.lib().bt_rng_normal_fill if kind == "normal" else _lib.lib().bt_rng_sign_fill
-    _lib.check(fn(C.byref(R), tensor_id, S, n, out.data_ptr(), _lib.stream_ptr()))
+def _rng(seed, call, layer_id, sample0, call_base):
+    return _lib.bt_rng(int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(call_base), int(call) & 0xFFFFFFFF, int(layer_id), int(sample0), 0)
+
+
+def rng_fill_normal(seed, call, layer_id, sample0, tensor_id, S, shape, device, call_base=None):
+    """Materialise the on-chip eps stream of a weight ([Co, Ci/g, kh, kw] or [Out, In]) or bias ([Co]) tensor
+    -> [S, *shape].  The stream is tap-major (include/bt_hip.h), the returned tensor is in natural order."""
+    shape = tuple(shape)
+    rows, inner = shape[0], (shape[1] if len(shape) > 1 else 1)
+    taps = 1
+    for d in shape[2:]:
+        taps *= d
+    out = torch.empty((S,) + shape, dtype=torch.float32, device=device)
+    R = _rng(seed, call, layer_id, sample0, call_base)
+    _lib.check(_lib.lib().bt_rng_normal_fill(C.byref(R), tensor_id, S, rows, inner, taps, out.data_ptr(), _lib.stream_ptr()))
+    return out
+
+
+def rng_fill_sign(seed, call, layer_id, sample0, tensor_id, S, shape, device, call_base=None):
+    """Materialise the on-chip Flipout sign stream (tensor_id 2: sign_in over one sample's x, 3: sign_out) -> [S, *shape]."""
+    shape = tuple(shape)
+    n = 1
+    for d in shape:
+        n *= d
+    out = torch.empty((S,) + shape, dtype=torch.float32, device=device)
+    R = _rng(seed, call, layer_id, sample0, call_base)
+    _lib.check(_lib.lib().bt_rng_sign_fill(C.byref(R), tensor_id, S, n, out.data_ptr(), _lib.stream_ptr()))
     return out
 
 

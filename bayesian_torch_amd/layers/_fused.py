@@ -223,21 +223,10 @@ class FusedBayesLayer(BaseVariationalLayer_):
         if call_base is not None:
             raise RuntimeError("draws made under a graph call_base cannot be replayed after the word advanced")
         dev = self._w("mu").device
-        R = _lib.bt_rng(seed, None, call, lid, sample0, 0)
-        L = _lib.lib()
-        nw = self._w("mu").numel()
-        res = {}
-        e = torch.empty((S,) + wshape, device=dev)
-        _lib.check(L.bt_rng_normal_fill(C.byref(R), 0, S, nw, e.data_ptr(), _lib.stream_ptr()))
-        res["eps_w"] = e
+        res = dict(eps_w=F.rng_fill_normal(seed, call, lid, sample0, 0, S, wshape, dev))
         if self.mu_bias is not None:
-            eb = torch.empty((S, wshape[0]), device=dev)
-            _lib.check(L.bt_rng_normal_fill(C.byref(R), 1, S, wshape[0], eb.data_ptr(), _lib.stream_ptr()))
-            res["eps_b"] = eb
+            res["eps_b"] = F.rng_fill_normal(seed, call, lid, sample0, 1, S, (wshape[0],), dev)
         if self._flip:
-            si = torch.empty((S,) + st["x_shape"], device=dev)
-            so = torch.empty((S,) + st["out_shape"], device=dev)
-            _lib.check(L.bt_rng_sign_fill(C.byref(R), 2, S, si[0].numel(), si.data_ptr(), _lib.stream_ptr()))
-            _lib.check(L.bt_rng_sign_fill(C.byref(R), 3, S, so[0].numel(), so.data_ptr(), _lib.stream_ptr()))
-            res["sign_in"], res["sign_out"] = si, so
+            res["sign_in"] = F.rng_fill_sign(seed, call, lid, sample0, 2, S, st["x_shape"], dev)
+            res["sign_out"] = F.rng_fill_sign(seed, call, lid, sample0, 3, S, st["out_shape"], dev)
         return res

@@ -151,9 +151,15 @@ int bt_kl_normal(int32_t n_segments, const float *const *mu, const float *const 
                  uint32_t flags, float *kl_out /* [1] */, void *workspace, size_t workspace_bytes, bt_stream_t stream);
 
 /* The on-chip draws, materialised (test / replay hook: the fused kernels never call these).
- * They emit exactly the stream the fused kernels consume for (rng, tensor_id):
- * tensor_id 0 = eps_w, 1 = eps_b, 2 = sign_in, 3 = sign_out. out is [S][n]. */
-int bt_rng_normal_fill(const bt_rng *rng, uint32_t tensor_id, int32_t S, int64_t n, float *out, bt_stream_t stream);
+ * They emit exactly the streams the fused kernels consume for (rng, tensor_id):
+ * tensor_id 0 = eps_w, 1 = eps_b, 2 = sign_in, 3 = sign_out.
+ * Stream definition. eps element (row r, inner index c, tap t) of a [rows][inner][taps] tensor (a conv kernel
+ * [Co][Ci/g][kh*kw]; Linear and bias: taps = 1) is normal number (e & 3) of Philox block (e >> 2) with
+ * e = (r*taps + t)*inner + c  -- tap-major, so the 4 values of one Philox block are 4 consecutive input channels
+ * of ONE tap and a kernel that skips taps which only ever meet zero padding skips their RNG as well.
+ * out is [S][rows*inner*taps] in the tensor's natural memory order. Signs: element i of the flat tensor. */
+int bt_rng_normal_fill(const bt_rng *rng, uint32_t tensor_id, int32_t S, int64_t rows, int64_t inner, int64_t taps,
+                       float *out, bt_stream_t stream);
 int bt_rng_sign_fill(const bt_rng *rng, uint32_t tensor_id, int32_t S, int64_t n, float *out, bt_stream_t stream);
 int bt_rng_philox_raw(uint64_t seed, const uint32_t ctr[4], uint32_t out_host[4]); /* host-side Philox4x32-10 KAT hook */
 

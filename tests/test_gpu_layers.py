@@ -95,11 +95,11 @@ def test_philox_mode_replays_through_oracle(name):
                              conv=g["conv"], S=S, seed=seed, call=call, layer_id=lid, sample0=s0)
     out = out.reshape((S,) + tuple(g["out"].shape)).cpu()
     dev = torch.device("cuda")
-    eps_w = F.rng_fill("normal", seed, call, lid, s0, 0, S, g["mu_w"].numel(), dev).cpu().reshape((S,) + tuple(g["mu_w"].shape))
-    eps_b = F.rng_fill("normal", seed, call, lid, s0, 1, S, g["mu_w"].shape[0], dev).cpu() if g["mu_b"] is not None else None
+    eps_w = F.rng_fill_normal(seed, call, lid, s0, 0, S, g["mu_w"].shape, dev).cpu()
+    eps_b = F.rng_fill_normal(seed, call, lid, s0, 1, S, (g["mu_w"].shape[0],), dev).cpu() if g["mu_b"] is not None else None
     if flip:
-        s_in = F.rng_fill("sign", seed, call, lid, s0, 2, S, g["x"].numel(), dev).cpu().reshape((S,) + tuple(g["x"].shape))
-        s_out = F.rng_fill("sign", seed, call, lid, s0, 3, S, g["out"].numel(), dev).cpu().reshape((S,) + tuple(g["out"].shape))
+        s_in = F.rng_fill_sign(seed, call, lid, s0, 2, S, g["x"].shape, dev).cpu()
+        s_out = F.rng_fill_sign(seed, call, lid, s0, 3, S, g["out"].shape, dev).cpu()
     for s in range(S):
         eb = None if eps_b is None else eps_b[s]
         if flip:
@@ -136,21 +136,25 @@ def test_rng_streams_statistics():
     from bayesian_torch_amd import functional as F
     dev = torch.device("cuda")
     n = 1 << 20
-    z = F.rng_fill("normal", 2024, 0, 1, 0, 0, 4, n, dev)
+    z = F.rng_fill_normal(2024, 0, 1, 0, 0, 4, (n,), dev)
     assert abs(float(z.mean())) < 3e-3 and abs(float(z.std()) - 1) < 3e-3
     assert abs(float((z ** 3).mean())) < 1e-2 and abs(float((z ** 4).mean()) - 3) < 3e-2
     c = torch.corrcoef(z)                      # independence across samples
     assert float((c - torch.eye(4, device=dev)).abs().max()) < 5e-3
     assert abs(float((z[0, 1:] * z[0, :-1]).mean())) < 5e-3      # lag-1
-    z2 = F.rng_fill("normal", 2024, 1, 1, 0, 0, 1, n, dev)       # next call: a fresh stream
+    z2 = F.rng_fill_normal(2024, 1, 1, 0, 0, 1, (n,), dev)       # next call: a fresh stream
     assert abs(float((z2[0] * z[0]).mean())) < 5e-3
-    s = F.rng_fill("sign", 2024, 0, 1, 0, 2, 4, n, dev)
+    s = F.rng_fill_sign(2024, 0, 1, 0, 2, 4, (n,), dev)
+    zc = F.rng_fill_normal(2024, 0, 1, 0, 0, 1, (64, 32, 3, 3), dev)[0]   # conv-shaped: the tap-major stream, natural layout
+    assert abs(float(zc.mean())) < 2e-2 and abs(float(zc.std()) - 1) < 2e-2
+    flat = F.rng_fill_normal(2024, 0, 1, 0, 0, 1, (64 * 9 * 32,), dev)[0]   # same Philox blocks, e-order
+    assert torch.equal(zc.permute(0, 2, 3, 1).reshape(-1), flat)
     assert bool(((s == 1) | (s == -1)).all())
     assert abs(float(s.mean())) < 3e-3
     assert float((torch.corrcoef(s) - torch.eye(4, device=dev)).abs().max()) < 5e-3
     assert abs(float((s[0, 1:] * s[0, :-1]).mean())) < 5e-3
     # reproducible
-    assert torch.equal(z, F.rng_fill("normal", 2024, 0, 1, 0, 0, 4, n, dev))
+    assert torch.equal(z, F.rng_fill_normal(2024, 0, 1, 0, 0, 4, (n,), dev))
 
 
 def test_mc_epilogue_matches_oracle():
