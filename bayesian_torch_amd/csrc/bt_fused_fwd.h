@@ -56,6 +56,7 @@ struct FwdArgs {
   const float *ep_scale, *ep_shift, *ep_res;  // fused output stage (bt_epilogue)
   long long ep_res_stride;
   int ep_relu;
+  unsigned long long* dbg;  // diagnostic stamps (bt_debug_set_stamp_buffer); null in normal operation
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2). Give every XCD a CONTIGUOUS range of
@@ -468,10 +469,14 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
   // The two roles are separate control-flow arms with the same number of workgroup barriers, so the accumulator
   // registers live only in the consumer arm and the producer arm gets the whole register budget for loads in flight.
   if (producer) {
+    const bool stamp = a.dbg && blockIdx.x == 0 && tid == 256;
     for (int st = 0; st <= NS; ++st) {  // NS + 1 barriers, like the consumer arm
+      if (stamp && st < 60) a.dbg[128 + 2 * st] = __builtin_amdgcn_s_memtime();
       if (st < NS) produce_stage(st, (st & 1) ? buf1 : buf0);
+      if (stamp && st < 60) a.dbg[128 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
       __syncthreads();
     }
+    if (stamp) a.dbg[127] = __builtin_amdgcn_s_memtime();
     // bias draw for this workgroup's output channels
     if (ptid < BN) {
       float b0 = 0.f, b1 = 0.f;
@@ -535,10 +540,15 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
         for (int j = 0; j < TM; ++j)
   #pragma unroll
           for (int r = 0; r < 16; ++r) acc[w][i][j][r] = 0.f;
+    const bool stamp = a.dbg && blockIdx.x == 0 && tid == 0;
+    if (stamp) a.dbg[0] = __builtin_amdgcn_s_memtime();
     for (int st = 0; st < NS; ++st) {  // one barrier per stage
+      if (stamp && st < 60) a.dbg[2 + 2 * st] = __builtin_amdgcn_s_memtime();
       consume(acc, st, (st & 1) ? buf1 : buf0);
+      if (stamp && st < 60) a.dbg[2 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
       __syncthreads();
     }
+    if (stamp) a.dbg[1] = __builtin_amdgcn_s_memtime();
     __syncthreads();  // the producers have staged the bias
 
     // output stage + store
@@ -607,6 +617,7 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
     }
   }
 
+  if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[126] = __builtin_amdgcn_s_memtime();
   // ---- KL finish ------------------------------------------------------------------------------------------------------------
   if (!kl_block) return;
   const double bsum = block_sum_all(kl_acc, red);

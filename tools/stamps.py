@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Per-stage timeline of block 0 (diagnostic build hook bt_debug_set_stamp_buffer)."""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bayesian_torch_amd import _lib, functional as F
+sys.argv = [sys.argv[0]] + sys.argv[1:]
+import argparse
+ap = argparse.ArgumentParser(); ap.add_argument("--shape", default="layer1"); ap.add_argument("--S", type=int, default=32); ap.add_argument("--B", type=int, default=128)
+a = ap.parse_args()
+SH = {"conv1": (3, 64, 7, 2, 3, 32), "layer1": (64, 64, 3, 1, 1, 8), "layer2": (128, 128, 3, 1, 1, 4), "layer3": (256, 256, 3, 1, 1, 2), "layer4": (512, 512, 3, 1, 1, 1)}
+Ci, Co, k, st, pd, H = SH[a.shape]
+dev = torch.device("cuda")
+mu = torch.randn(Co, Ci, k, k, device=dev) * 0.1; rho = torch.randn(Co, Ci, k, k, device=dev) * 0.1 - 3
+x = torch.randn(a.S * a.B, Ci, H, H, device=dev)
+conv = dict(stride=(st, st), padding=(pd, pd), dilation=(1, 1), groups=1)
+buf = torch.zeros(256, dtype=torch.int64, device=dev)
+L = _lib.lib(); L.bt_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]; L.bt_debug_set_stamp_buffer.restype = None
+for i in range(3):
+    F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=i, layer_id=3)
+L.bt_debug_set_stamp_buffer(buf.data_ptr())
+F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=9, layer_id=3)
+torch.cuda.synchronize()
+L.bt_debug_set_stamp_buffer(None)
+t = buf.cpu().tolist()
+t0 = t[0]
+print("s_memtime ticks (100 MHz realtime? or shader clock) relative to consumer loop start")
+print("consumer: loop", t[1] - t0, "end-of-kernel", t[126] - t0)
+for s in range(60):
+    if t[2 + 2 * s] == 0: break
+    c0, c1, p0, p1 = t[2 + 2 * s] - t0, t[3 + 2 * s] - t0, t[128 + 2 * s] - t0, t[129 + 2 * s] - t0
+    print(f"st {s:2d}  consumer [{c0:7d} .. {c1:7d}] = {c1-c0:6d}   producer [{p0:7d} .. {p1:7d}] = {p1-p0:6d}")
