@@ -50,10 +50,9 @@ static int pick_tile(FwdArgs& a, hipStream_t stream) {
   if (Mdom <= 32) return launch_cfg<128, 32, 4, FLIP, LINEAR, TRANS, INJ>(a, stream);
   if (Mdom <= 64) return launch_cfg<64, 64, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);
   if (a.Cog <= 32) return launch_cfg<32, 128, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
-  if constexpr (!FLIP) {  // 256-wide tiles: one accumulator set fits (Flipout carries two)
-    if (Mdom >= 256) {
-      if (tiles_for(a, 64, 256) >= kCUs) return launch_cfg<64, 256, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
-    }
+  if constexpr (!FLIP) {  // wide tiles: one accumulator set fits in the consumers' registers (Flipout carries two)
+    if (Mdom >= 256 && a.Cog > 64 && tiles_for(a, 128, 256) >= kCUs) return launch_cfg<128, 256, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);
+    if (Mdom >= 256 && tiles_for(a, 64, 256) >= kCUs) return launch_cfg<64, 256, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
   }
   if (a.Cog > 64 && tiles_for(a, 128, 128) >= kCUs) return launch_cfg<128, 128, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);
   return launch_cfg<64, 128, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);

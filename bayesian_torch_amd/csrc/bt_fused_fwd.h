@@ -34,11 +34,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBK = 36;        // K rows of one LDS stage (9 taps x 4 channels)
 constexpr int kMaxTaps = 128;  // kh*kw supported by the tap table
-constexpr int kThreads = 768;   // 4 consumer waves (one per SIMD) + 8 producer waves (two per SIMD)
-constexpr int kProducers = 512;
+constexpr int kThreads = 512;   // 4 consumer waves + 4 producer waves: one of each per SIMD
+constexpr int kProducers = 256;
 
 struct FwdArgs {
   const float *x, *mu_w, *rho_w, *mu_b, *rho_b, *pmu_w, *psig_w, *pmu_b, *psig_b;
+  const float* sigma_w;  // optional cached log1p(exp(rho_w)) (bt_params.sigma_w); null: computed in the kernel
   const float *eps_w, *eps_b, *sign_in, *sign_out;
   float* out;
   float* kl_out;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
   constexpr int WS = BN + 1, XS = BM + 1;  // odd strides: the transposed ds_write_b32 scatter stays (nearly) conflict-free
   constexpr int NW = FLIP ? 2 : 1;
   constexpr int W_WORDS = kBK * WS, X_WORDS = kBK * XS, BUF_WORDS = NW * (W_WORDS + X_WORDS);
-  static_assert(TN >= 1 && TM >= 1 && BN % 32 == 0 && BM % 32 == 0 && BM <= 256, "tile shape");
+  static_assert(TN >= 1 && TM >= 1 && BN % 32 == 0 && BM % 32 == 0 && WTM * CWM == BM && WTN * CWN == BN && BM <= kProducers, "tile shape");
   static_assert(!LINEAR || TRANS, "Linear always stores with lanes along the output features");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];  // ONE LDS object
@@ -211,11 +212,57 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
   }
   const bool quad_rng = (Cig & 3) == 0;  // 4 consecutive channels of one tap are exactly one Philox block
 
+  // ---- producer state hoisted out of the stage loop -----------------------------------------------------------------------
+  // Weight unit = (row r, channel quad cq, active tap slot ai) -> 4 sampled weights. The (r, cq, ai) of this thread's
+  // units depend only on the stage SHAPE (NA taps x CC channels), so they are decoded once; a stage whose tap chunk is
+  // short simply masks the slots past its last tap.
+  constexpr int UMAX = (BN * 9 + kProducers - 1) / kProducers;  // a stage holds at most 9 quads per row
+  const int ncq_ = CC >> 2, lncq_ = lcc - 2;
+  const int nunits_full = BN * ncq_ * NA;
+  int u_r[UMAX], u_ai[UMAX], u_kc[UMAX];
+  uint32_t u_wb[UMAX], u_eb[UMAX];  // row parts of the weight offset and of the draw index
+  unsigned u_ok = 0;                // bit i: unit i exists and its row is inside Cog
+  if (producer) {
+    const uint32_t inv_na = (uint32_t)((0x100000000ull + (unsigned)NA - 1) / (unsigned)NA);
+#pragma unroll
+    for (int i = 0; i < UMAX; ++i) {
+      const int u = ptid + kProducers * i;
+      const int uu = u < nunits_full ? u : 0;
+      const int tq = NA == 1 ? uu : (int)__umulhi((uint32_t)uu, inv_na);  // uu / NA (exact for uu < 2^16; 2^32/1 does not fit)
+      const int ai = uu - tq * NA;
+      const int cq = tq & (ncq_ - 1), r = tq >> lncq_;
+      const int co_g = n0 + r;
+      const uint32_t co = (uint32_t)(g * a.Cog + (co_g < a.Cog ? co_g : 0));
+      u_r[i] = r;
+      u_ai[i] = ai;
+      u_kc[i] = (ai << lcc) + 4 * cq;
+      u_wb[i] = co * (uint32_t)K + (uint32_t)(4 * cq * T);
+      u_eb[i] = co * (uint32_t)T * (uint32_t)Cig + (uint32_t)(4 * cq);
+      if (u < nunits_full && co_g < a.Cog) u_ok |= 1u << i;
+    }
+  }
+  const int wave_u0 = __builtin_amdgcn_readfirstlane(ptid & ~63);  // first unit index of this wave (iteration 0)
+  // Gather descriptors per tap slot: offset of the tap inside an image plane + "this lane's pixel sees real data".
+  int g_off[9];
+  unsigned g_ok = 0;
+  auto setup_taps = [&](int a0, int na_s) {
+    g_ok = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int4 e = taptab[a0 + (t < na_s ? t : 0)];
+      g_off[t] = xoff0 + e.x;
+      if (mvalid && t < na_s && (unsigned)(hi0 + e.y) < (unsigned)a.H && (unsigned)(wi0 + e.z) < (unsigned)a.W) g_ok |= 1u << t;
+    }
+  };
+  if (!LINEAR && producer && n_ach == 1) setup_taps(0, nA);
+  const float* const sig_or_rho = a.sigma_w ? a.sigma_w : a.rho_w;
+  const bool have_sigma = a.sigma_w != nullptr;
+
   // One stage of producer work. All global loads of the stage (weights, then activations) are issued before any of
-  // them is consumed, unconditionally on clamped offsets (a load under a per-lane condition, or a runtime branch
-  // between two loads, makes hipcc wait for each one alone), and the Philox/Box-Muller arithmetic -- which depends
-  // on no load -- runs while they are in flight. LCC = log2(channels per stage) is a compile-time constant so that
-  // the gather is a static (tap, channel) nest: per tap one table read and one bounds test, per element ~5 instructions.
+  // them is consumed, unconditionally on clamped offsets and with no select between them (a load under a per-lane
+  // condition, or a use of its value before the next load, makes hipcc wait for each one alone); masking happens when
+  // the values are written to LDS. The Philox/Box-Muller arithmetic depends on no load and runs while they are in
+  // flight. LCC = log2(channels per stage) is a compile-time constant so that the gather is a static (tap, channel) nest.
   auto produce = [&](auto LCCc, int st, float* buf) {
     constexpr int LCC = decltype(LCCc)::value, CCs = 1 << LCC;
     float* const Wt0 = buf;
@@ -225,60 +272,44 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
     const int cch = st / n_ach, ach = st - cch * n_ach;
     const int a0 = ach * NA, c0 = cch * CCs;
     const int na_s = (nA - a0) < NA ? (nA - a0) : NA;
-    // -------- weights: unit = (row r, channel quad cq, active tap ai) -> 4 sampled weights -------------------------
-    constexpr int UMAX = (BN * 9 + kProducers - 1) / kProducers;  // a stage holds at most 9 quads per row
-    constexpr int ncq = CCs >> 2, lncq = LCC - 2;
-    const int nunits = BN * ncq * na_s;
-    const uint32_t inv_na = (uint32_t)((0x100000000ull + (unsigned)na_s - 1) / (unsigned)na_s);
-    float mu[UMAX][4], rho[UMAX][4], ep[UMAX][4];
-    int urow[UMAX], ukc[UMAX];
+    const bool pst = a.dbg && blockIdx.x == 0 && tid == 256 && st == 3;
+    if (pst) a.dbg[250] = __builtin_amdgcn_s_memtime();
+    if (!LINEAR && n_ach > 1) setup_taps(a0, na_s);
+    // -------- weights: loads -----------------------------------------------------------------------------------------------
+    float mu[UMAX][4], rs[UMAX][4], ep[UMAX][4];
     uint32_t ue0[UMAX];
-    unsigned uval[UMAX];  // bit j: element j exists; bit 4: row exists; bit 5: no unit at all
+    unsigned uval[UMAX];  // bit j: element j exists
 #pragma unroll
     for (int i = 0; i < UMAX; ++i) {
-      const int u = ptid + kProducers * i;
-      const int uu = u < nunits ? u : 0;
-      const int tq = na_s == 1 ? uu : (int)__umulhi((uint32_t)uu, inv_na);  // uu / na_s (exact for uu < 2^16; 2^32/1 does not fit)
-      const int ai = uu - tq * na_s;
-      const int cq = tq & (ncq - 1), r = tq >> lncq;
-      const int tap = LINEAR ? 0 : taptab[a0 + ai].w;
-      const int co_g = n0 + r, ci = c0 + 4 * cq;
-      const bool rv = (u < nunits) && (co_g < a.Cog);
-      const uint32_t co = (uint32_t)(g * a.Cog + co_g);
-      const uint32_t base = co * (uint32_t)K + (uint32_t)(ci * T + tap);  // natural [co][ci][tap] offset of channel ci
-      ue0[i] = (co * (uint32_t)T + (uint32_t)tap) * (uint32_t)Cig + (uint32_t)ci;  // tap-major draw index of channel ci
-      urow[i] = r;
-      ukc[i] = (ai << LCC) + 4 * cq;
-      unsigned val = rv ? 16u : 0u;
+      uval[i] = 0;
+      if (i == 0 || wave_u0 + kProducers * i < nunits_full) {  // wave-uniform: later iterations are mostly empty
+        const int tap = LINEAR ? 0 : taptab[a0 + (u_ai[i] < na_s ? u_ai[i] : 0)].w;
+        const int ci = c0 + ((u_kc[i]) & (CCs - 1));
+        const bool uv = ((u_ok >> i) & 1u) && u_ai[i] < na_s;
+        const uint32_t base = u_wb[i] + (uint32_t)(c0 * T + tap);           // natural [co][ci][tap] offset of channel ci
+        ue0[i] = u_eb[i] + (uint32_t)(tap * Cig + c0);                        // tap-major draw index of channel ci
+        unsigned val = 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ep[i][j] = 0.f;
-        if (rv && (ci + j < Cig)) val |= 1u << j;
-      }
-      if (u >= nunits) val = 32u;
-      uval[i] = val;
-      if constexpr (LINEAR) {  // the quad is contiguous and all-in or all-out
-        const bool in = (val & 1u) != 0;
-        const uint32_t sb = in ? base : 0u;
-        const float4 m4 = *reinterpret_cast<const float4*>(a.mu_w + sb);
-        const float4 r4 = *reinterpret_cast<const float4*>(a.rho_w + sb);
-        mu[i][0] = in ? m4.x : 0.f, mu[i][1] = in ? m4.y : 0.f, mu[i][2] = in ? m4.z : 0.f, mu[i][3] = in ? m4.w : 0.f;
-        rho[i][0] = in ? r4.x : 0.f, rho[i][1] = in ? r4.y : 0.f, rho[i][2] = in ? r4.z : 0.f, rho[i][3] = in ? r4.w : 0.f;
-        if constexpr (INJ) {
-          const float4 e4 = *reinterpret_cast<const float4*>(eps_w_s + sb);
-          ep[i][0] = in ? e4.x : 0.f, ep[i][1] = in ? e4.y : 0.f, ep[i][2] = in ? e4.z : 0.f, ep[i][3] = in ? e4.w : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bool in = (val >> j) & 1u;
-          const uint32_t sb = in ? base + (uint32_t)(j * T) : 0u;
-          const float m1 = a.mu_w[sb], r1 = a.rho_w[sb];
-          mu[i][j] = in ? m1 : 0.f;
-          rho[i][j] = in ? r1 : 0.f;
+        for (int j = 0; j < 4; ++j)
+          if (uv && (ci + j < Cig)) val |= 1u << j;
+        uval[i] = val;
+        if constexpr (LINEAR) {  // the quad is contiguous and all-in or all-out
+          const uint32_t sb = (val & 1u) ? base : 0u;
+          const float4 m4 = *reinterpret_cast<const float4*>(a.mu_w + sb);
+          const float4 r4 = *reinterpret_cast<const float4*>(sig_or_rho + sb);
+          mu[i][0] = m4.x, mu[i][1] = m4.y, mu[i][2] = m4.z, mu[i][3] = m4.w;
+          rs[i][0] = r4.x, rs[i][1] = r4.y, rs[i][2] = r4.z, rs[i][3] = r4.w;
           if constexpr (INJ) {
-            const float e1 = eps_w_s[sb];
-            ep[i][j] = in ? e1 : 0.f;
+            const float4 e4 = *reinterpret_cast<const float4*>(eps_w_s + sb);
+            ep[i][0] = e4.x, ep[i][1] = e4.y, ep[i][2] = e4.z, ep[i][3] = e4.w;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t sb = ((val >> j) & 1u) ? base + (uint32_t)(j * T) : 0u;
+            mu[i][j] = a.mu_w[sb];
+            rs[i][j] = sig_or_rho[sb];
+            if constexpr (INJ) ep[i][j] = eps_w_s[sb];
           }
         }
       }
@@ -291,6 +322,7 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
     constexpr int NXR = LINEAR ? ((BM + RP - 1) / RP) * 4 : (FASTX ? TPS * CPT : (kBK + NG - 1) / NG);
     float xv[NXR], xs_[FLIP ? NXR : 1];
     uint32_t xo[FLIP ? NXR : 1];
+    unsigned long long xok = 0;  // bit q: element q is real data (else zero padding / outside the tile)
     if constexpr (LINEAR) {
       const int kq = ptid & 7, mr = ptid >> 3;
 #pragma unroll
@@ -299,9 +331,10 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
         const int m = m0 + rl, k = c0 + 4 * kq;
         const uint32_t off = (uint32_t)m * (uint32_t)K + (uint32_t)k;
         const bool in = rl < BM && m < a.M && k < K;
+        if (in) xok |= 0xFull << (4 * p);
         const uint32_t so = in ? off : 0u;
         const float4 x4 = *reinterpret_cast<const float4*>(xs + so);
-        xv[4 * p] = in ? x4.x : 0.f, xv[4 * p + 1] = in ? x4.y : 0.f, xv[4 * p + 2] = in ? x4.z : 0.f, xv[4 * p + 3] = in ? x4.w : 0.f;
+        xv[4 * p] = x4.x, xv[4 * p + 1] = x4.y, xv[4 * p + 2] = x4.z, xv[4 * p + 3] = x4.w;
         if constexpr (FLIP) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) xo[4 * p + j] = off + j;
@@ -312,18 +345,16 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
         }
       }
     } else if constexpr (FASTX) {
+      const int ci0 = c0 + xg;
+      const int cbase = ci0 * a.HW;
 #pragma unroll
       for (int t = 0; t < TPS; ++t) {
-        const int4 e = taptab[a0 + (t < na_s ? t : 0)];
-        const bool okt = mvalid && t < na_s && (unsigned)(hi0 + e.y) < (unsigned)a.H && (unsigned)(wi0 + e.z) < (unsigned)a.W;
-        const int ci0 = c0 + xg;
-        const int base = xoff0 + e.x + ci0 * a.HW;
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-          const bool ok = okt && (ci0 + c * NG < Cig);
-          const uint32_t off = ok ? (uint32_t)(base + c * NG * a.HW) : 0u;
-          const float x1 = xs[off];
-          xv[t * CPT + c] = ok ? x1 : 0.f;
+          const bool ok = ((g_ok >> t) & 1u) && (ci0 + c * NG < Cig);
+          if (ok) xok |= 1ull << (t * CPT + c);
+          const uint32_t off = ok ? (uint32_t)(g_off[t] + cbase + c * NG * a.HW) : 0u;
+          xv[t * CPT + c] = xs[off];
           if constexpr (FLIP) {
             xo[t * CPT + c] = off;
             if constexpr (INJ) xs_[t * CPT + c] = sin_s[off];
@@ -338,21 +369,22 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
         const int4 e = taptab[a0 + (kc < KC ? (kc >> LCC) : 0)];
         const int ci = c0 + (kc & (CCs - 1));
         const bool ok = mvalid && kc < KC && ci < Cig && (unsigned)(hi0 + e.y) < (unsigned)a.H && (unsigned)(wi0 + e.z) < (unsigned)a.W;
+        if (ok) xok |= 1ull << q;
         const uint32_t off = ok ? (uint32_t)(xoff0 + ci * a.HW + e.x) : 0u;
-        const float x1 = xs[off];
-        xv[q] = ok ? x1 : 0.f;
+        xv[q] = xs[off];
         if constexpr (FLIP) {
           xo[q] = off;
           if constexpr (INJ) xs_[q] = sin_s[off];
         }
       }
     }
+    if (pst) a.dbg[251] = __builtin_amdgcn_s_memtime();
     // -------- draws (independent of every load above) ----------------------------------------------------------------------
     if constexpr (!INJ) {
       if (quad_rng) {
 #pragma unroll
         for (int i = 0; i < UMAX; ++i)
-          if (uval[i] & 16u) philox_normal4(key_w, sample, ue0[i] >> 2, ep[i]);
+          if (uval[i]) philox_normal4(key_w, sample, ue0[i] >> 2, ep[i]);
       } else {
 #pragma unroll
         for (int i = 0; i < UMAX; ++i)
@@ -366,20 +398,25 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
             }
       }
     }
+    if (pst) a.dbg[252] = __builtin_amdgcn_s_memtime();
     // -------- sampled weights -> LDS (transposed) ---------------------------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < UMAX; ++i) {
-      if (!(uval[i] & 32u)) {
+      if (i == 0 || wave_u0 + kProducers * i < nunits_full) {
+        if (ptid + kProducers * i < nunits_full && u_ai[i] < na_s) {  // every slot of the stage is written (zeros when masked)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bool ev = (uval[i] >> j) & 1u;
-          const float dl = __fmul_rn(softplus(rho[i][j]), ep[i][j]);
-          const float w0 = FLIP ? mu[i][j] : __fadd_rn(mu[i][j], dl);
-          Wt0[(ukc[i] + j) * WS + urow[i]] = ev ? w0 : 0.f;
-          if (FLIP) Wt1[(ukc[i] + j) * WS + urow[i]] = ev ? dl : 0.f;
+          for (int j = 0; j < 4; ++j) {
+            const bool ev = (uval[i] >> j) & 1u;
+            const float sg = have_sigma ? rs[i][j] : softplus(rs[i][j]);
+            const float dl = __fmul_rn(sg, ev ? ep[i][j] : 0.f);
+            const float w0 = FLIP ? mu[i][j] : __fadd_rn(mu[i][j], dl);
+            Wt0[(u_kc[i] + j) * WS + u_r[i]] = ev ? w0 : 0.f;
+            if (FLIP) Wt1[(u_kc[i] + j) * WS + u_r[i]] = ev ? dl : 0.f;
+          }
         }
       }
     }
+    if (pst) a.dbg[253] = __builtin_amdgcn_s_memtime();
     // -------- activations -> LDS -------------------------------------------------------------------------------------------------
     if constexpr (LINEAR) {
       const int kq = ptid & 7, mr = ptid >> 3;
@@ -390,8 +427,9 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int idx = (4 * kq + j) * XS + rl;
-            Xt0[idx] = xv[4 * p + j];
-            if (FLIP) Xt1[idx] = __fmul_rn(xv[4 * p + j], INJ ? xs_[4 * p + j] : hash_sign(skey_in, xo[4 * p + j]));
+            const float v = ((xok >> (4 * p + j)) & 1ull) ? xv[4 * p + j] : 0.f;
+            Xt0[idx] = v;
+            if (FLIP) Xt1[idx] = __fmul_rn(v, INJ ? xs_[4 * p + j] : hash_sign(skey_in, xo[4 * p + j]));
           }
         }
       }
@@ -401,8 +439,9 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {  // rows past the stage's last tap are written too (never read; inside the buffer)
           const int idx = ((t << LCC) + xg + c * NG) * XS + xm;
-          Xt0[idx] = xv[t * CPT + c];
-          if (FLIP) Xt1[idx] = __fmul_rn(xv[t * CPT + c], INJ ? xs_[t * CPT + c] : hash_sign(skey_in, xo[t * CPT + c]));
+          const float v = ((xok >> (t * CPT + c)) & 1ull) ? xv[t * CPT + c] : 0.f;
+          Xt0[idx] = v;
+          if (FLIP) Xt1[idx] = __fmul_rn(v, INJ ? xs_[t * CPT + c] : hash_sign(skey_in, xo[t * CPT + c]));
         }
     } else {
       const int KC = na_s << LCC;
@@ -410,13 +449,15 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
       for (int q = 0; q < NXR; ++q) {
         const int kc = xg + q * NG;
         if (kc < KC) {
-          Xt0[kc * XS + xm] = xv[q];
-          if (FLIP) Xt1[kc * XS + xm] = __fmul_rn(xv[q], INJ ? xs_[q] : hash_sign(skey_in, xo[q]));
+          const float v = ((xok >> q) & 1ull) ? xv[q] : 0.f;
+          Xt0[kc * XS + xm] = v;
+          if (FLIP) Xt1[kc * XS + xm] = __fmul_rn(v, INJ ? xs_[q] : hash_sign(skey_in, xo[q]));
         }
       }
     }
   };
   auto produce_stage = [&](int st, float* buf) {
+    // (diagnostic stamps 250..253 are written inside produce)
     switch (lcc) {
       case 2: produce(std::integral_constant<int, 2>{}, st, buf); break;
       case 3: produce(std::integral_constant<int, 3>{}, st, buf); break;
@@ -433,27 +474,40 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
     const int cch = st / n_ach, ach = st - cch * n_ach;
     const int na_s = (nA - ach * NA) < NA ? (nA - ach * NA) : NA;
     const int KC = na_s << lcc;  // even (CC >= 4)
-#pragma unroll 2
-    for (int kk = 0; kk < KC; kk += 2) {
-      float af[NW][TN], bf[NW][TM];
+    // fragments of step kk + 2 are read from LDS while the MFMAs of step kk execute
+    float af[2][NW][TN], bf[2][NW][TM];
+    auto load_frags = [&](auto slotc, int kk) {
+      constexpr int slot = decltype(slotc)::value;
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
-        af[0][i] = Wt0[(kk + lh) * WS + i * 32];
-        if (FLIP) af[NW - 1][i] = Wt1[(kk + lh) * WS + i * 32];
+        af[slot][0][i] = Wt0[(kk + lh) * WS + i * 32];
+        if (FLIP) af[slot][NW - 1][i] = Wt1[(kk + lh) * WS + i * 32];
       }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        bf[0][j] = Xt0[(kk + lh) * XS + j * 32];
-        if (FLIP) bf[NW - 1][j] = Xt1[(kk + lh) * XS + j * 32];
+        bf[slot][0][j] = Xt0[(kk + lh) * XS + j * 32];
+        if (FLIP) bf[slot][NW - 1][j] = Xt1[(kk + lh) * XS + j * 32];
       }
+    };
+    auto mfmas = [&](auto slotc) {
+      constexpr int slot = decltype(slotc)::value;
 #pragma unroll
       for (int w = 0; w < NW; ++w)
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int j = 0; j < TM; ++j)
-            acc[w][i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[w][j], af[w][i], acc[w][i][j], 0, 0, 0)
-                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i], bf[w][j], acc[w][i][j], 0, 0, 0);
+            acc[w][i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[slot][w][j], af[slot][w][i], acc[w][i][j], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][w][i], bf[slot][w][j], acc[w][i][j], 0, 0, 0);
+    };
+    constexpr std::integral_constant<int, 0> s0{};
+    constexpr std::integral_constant<int, 1> s1{};
+    load_frags(s0, 0);
+    for (int kk = 0; kk < KC; kk += 4) {  // KC is a multiple of 4
+      load_frags(s1, kk + 2);
+      mfmas(s0);
+      if (kk + 4 < KC) load_frags(s0, kk + 4);
+      mfmas(s1);
     }
   };
 

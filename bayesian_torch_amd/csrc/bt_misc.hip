@@ -44,6 +44,10 @@ __global__ __launch_bounds__(256) void rng_sign_fill_kernel(RngKey k, const uint
     out[(long long)s * n + i] = hash_sign(key, (uint32_t)i);
 }
 
+__global__ __launch_bounds__(256) void softplus_kernel(const float* __restrict__ rho, float* __restrict__ sigma, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) sigma[i] = softplus(rho[i]);
+}
+
 // One block per batch row b: for each sample softmax over C classes, accumulate probabilities,
 // entropies and raw logits. C <= 4096 handled by striding; S loop is sequential (fixed order).
 __global__ __launch_bounds__(256) void mc_epilogue_kernel(int S, int B, int C, const float* __restrict__ logits, float* __restrict__ packed) {
@@ -135,4 +139,13 @@ extern "C" int bt_mc_epilogue(int32_t S, int32_t B, int32_t C, const float* logi
   if (S <= 0 || B <= 0 || C <= 0 || !logits || !packed) return set_error(BT_ERR_BAD_ARG, "bt_mc_epilogue: bad argument");
   hipLaunchKernelGGL(mc_epilogue_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, S, B, C, logits, packed);
   return check_launch("bt_mc_epilogue");
+}
+
+extern "C" int bt_softplus(const float* rho, float* sigma, int64_t n, bt_stream_t stream) {
+  using namespace bt;
+  if (!rho || !sigma || n <= 0) return set_error(BT_ERR_BAD_ARG, "bt_softplus: bad argument");
+  int gx = (int)((n + 255) / 256);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(softplus_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, rho, sigma, (long long)n);
+  return check_launch("bt_softplus");
 }

@@ -14,7 +14,7 @@ def conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, dh, dw):
 def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=None, S=1, shared_x=True,
                   priors=None, eps_w=None, eps_b=None, sign_in=None, sign_out=None,
                   seed=0, call=0, layer_id=0, sample0=0, call_base=None, want_kl=False, workspace_owner="functional",
-                  post_scale=None, post_shift=None, residual=None, relu=False):
+                  post_scale=None, post_shift=None, residual=None, relu=False, sigma_w=None):
     """x: [B, In] (conv=None) or [B, Ci, H, W]; when ``shared_x`` is False x holds S stacked batches
     ([S*B, ...]).  conv: dict(stride=(sh,sw), padding=(ph,pw), dilation=(dh,dw), groups=g) for Conv2d.
     priors: (prior_mu_w, prior_sigma_w, prior_mu_b, prior_sigma_b) -- required when want_kl.
@@ -24,7 +24,7 @@ def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=Non
     x = _lib.dev_f32(x, "input")
     dev = x.device
     tens = dict(mu_w=mu_w, rho_w=rho_w, mu_b=mu_b, rho_b=rho_b, eps_w=eps_w, eps_b=eps_b, sign_in=sign_in, sign_out=sign_out,
-                post_scale=post_scale, post_shift=post_shift, residual=residual)
+                post_scale=post_scale, post_shift=post_shift, residual=residual, sigma_w=sigma_w)
     for k, t in tens.items():
         t = _lib.dev_f32(t, k)
         if t is not None and t.device != dev:
@@ -61,7 +61,7 @@ def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=Non
         kl = torch.empty((), dtype=torch.float32, device=dev)
         ws = _lib.workspace(workspace_owner, dev)
     P = _lib.bt_params(tens["mu_w"].data_ptr(), tens["rho_w"].data_ptr(), _lib.ptr(tens["mu_b"]), _lib.ptr(tens["rho_b"]),
-                       _lib.ptr(pr[0]), _lib.ptr(pr[1]), _lib.ptr(pr[2]), _lib.ptr(pr[3]))
+                       _lib.ptr(pr[0]), _lib.ptr(pr[1]), _lib.ptr(pr[2]), _lib.ptr(pr[3]), _lib.ptr(tens["sigma_w"]))
     R = _lib.bt_rng(int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(call_base), int(call) & 0xFFFFFFFF, int(layer_id), int(sample0), 0)
     D = _lib.bt_draws(_lib.ptr(tens["eps_w"]), _lib.ptr(tens["eps_b"]), _lib.ptr(tens["sign_in"]), _lib.ptr(tens["sign_out"]), R)
     E = None
@@ -114,6 +114,14 @@ def rng_fill_sign(seed, call, layer_id, sample0, tensor_id, S, shape, device, ca
     out = torch.empty((S,) + shape, dtype=torch.float32, device=device)
     R = _rng(seed, call, layer_id, sample0, call_base)
     _lib.check(_lib.lib().bt_rng_sign_fill(C.byref(R), tensor_id, S, n, out.data_ptr(), _lib.stream_ptr()))
+    return out
+
+
+def softplus(rho):
+    """log1p(exp(rho)) with the kernels' device function (fills the sigma cache of a layer)."""
+    rho = _lib.dev_f32(rho, "rho")
+    out = torch.empty_like(rho)
+    _lib.check(_lib.lib().bt_softplus(rho.data_ptr(), out.data_ptr(), rho.numel(), _lib.stream_ptr()))
     return out
 
 

@@ -70,6 +70,8 @@ typedef struct bt_params {
   const float *mu_b, *rho_b; /* [Co] or both NULL */
   const float *prior_mu_w, *prior_sigma_w;
   const float *prior_mu_b, *prior_sigma_b;
+  const float *sigma_w; /* optional: log1p(exp(rho_w)) precomputed by bt_softplus (a cache of a pure function of rho_w;
+                           the kernel skips its own softplus). NULL: the kernel computes it from rho_w. */
 } bt_params;
 
 /* Injected draws (NULL => generate on chip). Layouts: eps_w [S][Co*K],
@@ -149,6 +151,10 @@ int bt_kl_normal(int32_t n_segments, const float *const *mu, const float *const 
                  const int32_t *layer_of_segment /* host, non-decreasing, or NULL: the fp32 sum is formed as
                                                     sum_layers( sum_{segments of layer} mean ) like get_kl_loss */,
                  uint32_t flags, float *kl_out /* [1] */, void *workspace, size_t workspace_bytes, bt_stream_t stream);
+
+/* sigma = log1p(exp(rho)) elementwise with the kernels' own device function (bit-identical to what a fused forward
+ * computes in place); fills the optional bt_params.sigma_w cache. */
+int bt_softplus(const float *rho, float *sigma, int64_t n, bt_stream_t stream);
 
 /* The on-chip draws, materialised (test / replay hook: the fused kernels never call these).
  * They emit exactly the streams the fused kernels consume for (rng, tensor_id):
