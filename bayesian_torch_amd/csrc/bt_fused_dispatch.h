@@ -1,23 +1,42 @@
 // Tile selection + launch for one FLIP flavour (included by bt_fused_reparam.hip / bt_fused_flipout.hip
 // so the two sets of instantiations compile in parallel).
 #pragma once
-#include "bt_fused_fwd.h"
+#include <stdlib.h>
+
+#include "bt_fused_fast.h"
 
 namespace bt {
 
-template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, bool INJ>
-static int launch_cfg(FwdArgs& a, hipStream_t stream) {
-  auto kern = fused_fwd_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, INJ>;
-  constexpr int lds = fused_lds_bytes<BN, BM, FLIP>();
-  static_assert(lds <= 160 * 1024, "LDS budget of one CU");
-  static bool attr_set[64] = {};
+// Can this launch run the specialised kernel (bt_fused_fast.h)?  Worst-case patch: every tap active.
+template <int BM, bool LINEAR>
+static bool fast_ok(const FwdArgs& a) {
+  static const bool forced_off = getenv("BT_FORCE_GENERIC") != nullptr;  // A/B hook for tests and benchmarks
+  if (forced_off || a.T > 9 || (a.Cig & 3) || a.w_elems >= (1ll << 29) || a.x_elems >= (1ll << 29)) return false;
+  if (LINEAR) return true;  // the LINEAR flavour is only dispatched when its float4 conditions hold
+  if (!(a.pixel_major || (a.HoWo <= BM && BM % a.HoWo == 0))) return false;
+  const int NI = a.pixel_major ? BM : BM / a.HoWo, R = a.pixel_major ? 1 : a.Ho, Wt = a.pixel_major ? 1 : a.Wo;
+  const int dys = (a.KH - 1) * a.DH, dxs = (a.KW - 1) * a.DW;
+  const long long PHt = (long long)(R - 1) * (dys ? a.SH : 1) + dys + 1, PWt = (long long)(Wt - 1) * (dxs ? a.SW : 1) + dxs + 1;
+  const long long PCH = NI * PHt * PWt;
+  return 4 * PCH <= (long long)kBK * (BM + 1) && PCH < 65536;
+}
+
+template <typename Kern>
+static int ensure_lds(Kern kern, int lds, bool* flags) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return set_error(BT_ERR_HIP_BASE, "fused forward: hipGetDevice failed");
-  if (!attr_set[dev]) {
+  if (!flags[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return set_error(BT_ERR_HIP_BASE, "fused forward: cannot raise the dynamic LDS limit");
-    attr_set[dev] = true;
+    flags[dev] = true;
   }
+  return BT_OK;
+}
+
+template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, bool INJ>
+static int launch_cfg(FwdArgs& a, hipStream_t stream) {
+  constexpr int lds = fused_lds_bytes<BN, BM, FLIP>();
+  static_assert(lds <= 160 * 1024, "LDS budget of one CU");
   a.n_tiles = (a.Cog + BN - 1) / BN;
   if (a.pixel_major) {
     a.mt_per_pixel = (a.B + BM - 1) / BM;
@@ -26,10 +45,23 @@ static int launch_cfg(FwdArgs& a, hipStream_t stream) {
     a.mt_per_pixel = 1;
     a.m_tiles = (a.M + BM - 1) / BM;
   }
+  a.patch_ok = (!LINEAR && (a.pixel_major || (a.HoWo <= BM && BM % a.HoWo == 0))) ? 1 : 0;
   const long long total = (long long)a.G * a.n_tiles * a.S * a.m_tiles;
   if (total <= 0 || total > 0x7FFFFFFFll) return set_error(BT_ERR_UNSUPPORTED, "fused forward: grid too large");
   a.total_blocks = (int)total;
   a.kl_slices = total < 4096 ? (int)total : 4096;
+  if constexpr (!INJ) {  // injected draws are the parity/debug mode: always the general kernel
+    if (fast_ok<BM, LINEAR>(a)) {
+      auto fk = fused_fast_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, false>;
+      static bool fflags[64] = {};
+      if (int rc = ensure_lds(fk, lds, fflags)) return rc;
+      hipLaunchKernelGGL(fk, dim3((unsigned)total), dim3(kThreads), lds, stream, a);
+      return check_launch("fused forward (fast)");
+    }
+  }
+  auto kern = fused_fwd_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, INJ>;
+  static bool gflags[64] = {};
+  if (int rc = ensure_lds(kern, lds, gflags)) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(kThreads), lds, stream, a);
   return check_launch("fused forward");
 }

@@ -1,0 +1,562 @@
+// Fast flavour of the fused forward (see bt_fused_fwd.h for the general one and the shared argument block).
+//
+// Same algorithm, specialised to what the convolution / linear layers of real models look like so that the producers'
+// steady-state loop is a handful of instructions per element on state that lives in VGPRs:
+//   * kh*kw <= 9  -> every active tap fits one K-stage: a stage is (CC channels) x (all active taps), identical for every
+//     channel chunk, so the unit decode, the tap of each unit, the patch geometry and the K-row table are computed ONCE;
+//   * Ci/groups % 4 == 0 -> the 4 channels of a weight unit are exactly one Philox block;
+//   * convolutions stage x as an LDS patch (each input pixel loaded once per stage, zero halo included), tiles are whole
+//     images or pixel-major; Linear stages its row-major tile with float4 loads.
+// Everything else (7x7 stems, odd channel counts, tiles that split images, > 2^16-element planes) runs the general kernel.
+#pragma once
+#include "bt_fused_fwd.h"
+
+namespace bt {
+
+template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, bool INJ>
+__global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
+  constexpr int CWM = 4 / CWN;
+  constexpr int WTN = BN / CWN, WTM = BM / CWM;
+  constexpr int TN = WTN / 32, TM = WTM / 32;
+  constexpr int WS = BN + 1, XS = BM + 1;
+  constexpr int NW = FLIP ? 2 : 1;
+  constexpr int W_WORDS = kBK * WS, X_WORDS = kBK * XS, BUF_WORDS = NW * (W_WORDS + X_WORDS);
+  static_assert(TN >= 1 && TM >= 1 && WTM * CWM == BM && WTN * CWN == BN && BM <= kProducers, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int4* const taptab = reinterpret_cast<int4*>(smem + 2 * BUF_WORDS);
+  double* const red = reinterpret_cast<double*>(smem + 2 * BUF_WORDS + kMaxTaps * 4);
+  int* const misc = reinterpret_cast<int*>(red + 12);
+  int* const rowtab = misc + 8;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const int ptid = producer ? tid - 256 : tid;
+  const int li = lane & 31, lh = lane >> 5;
+  const int cw = wave & 3, wn = cw / CWM, wm = cw % CWM;
+
+  int L = xcd_remap(blockIdx.x, a.total_blocks);
+  const int mt = L % a.m_tiles;
+  L /= a.m_tiles;
+  const int s = L % a.S;
+  L /= a.S;
+  const int nt = L % a.n_tiles;
+  const int g = L / a.n_tiles;
+  const int n0 = nt * BN;
+  const bool pix = a.pixel_major != 0;
+  const int tile_p = pix ? mt / a.mt_per_pixel : 0;
+  const int m0 = pix ? (mt - tile_p * a.mt_per_pixel) * BM : mt * BM;
+  const int m_lim = pix ? a.B : a.M;
+  const uint32_t sample = a.sample0 + (uint32_t)s;
+  const int K = a.K, T = a.T, Cig = a.Cig;
+
+  RngKey key_w;
+  key_w.seed_lo = a.seed_lo;
+  key_w.seed_hi = a.seed_hi;
+  key_w.call = a.call + (a.call_base ? __builtin_nontemporal_load(a.call_base) : 0u);
+  key_w.layer_tensor = layer_tensor_word(a.layer_id, 0);
+  uint32_t skey_in = 0, skey_out = 0;
+  if (FLIP && !INJ) {
+    RngKey ks = key_w;
+    ks.layer_tensor = layer_tensor_word(a.layer_id, 2);
+    skey_in = sign_stream_key(ks, sample);
+    ks.layer_tensor = layer_tensor_word(a.layer_id, 3);
+    skey_out = sign_stream_key(ks, sample);
+  }
+
+  // ---- active taps of this tile + their window (wave 0) ----------------------------------------------------------------
+  if (wave == 0) {
+    bool act = false;
+    int4 e = make_int4(0, 0, 0, 0);
+    if (lane < T) {
+      const int kh = lane / a.KW, kw = lane - kh * a.KW;
+      e = make_int4(0, kh * a.DH, kw * a.DW, lane);
+      if (LINEAR) {
+        act = true;
+      } else if (pix) {
+        const int ho = tile_p / a.Wo, wo = tile_p - ho * a.Wo;
+        act = (unsigned)(ho * a.SH - a.PH + e.y) < (unsigned)a.H && (unsigned)(wo * a.SW - a.PW + e.z) < (unsigned)a.W;
+      } else {
+        const int lo_h = a.PH - e.y, lo_w = a.PW - e.z;
+        const int hc = lo_h > 0 ? (lo_h + a.SH - 1) / a.SH : 0, wc = lo_w > 0 ? (lo_w + a.SW - 1) / a.SW : 0;
+        act = hc < a.Ho && hc * a.SH - lo_h < a.H && wc < a.Wo && wc * a.SW - lo_w < a.W;
+      }
+    }
+    const unsigned long long mask = __ballot(act);
+    if (act) taptab[__popcll(mask & ((1ull << lane) - 1ull))] = e;
+    int dy0 = act ? e.y : (1 << 20), dy1 = act ? e.y : -1, dx0 = act ? e.z : (1 << 20), dx1 = act ? e.z : -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      dy0 = min(dy0, __shfl_xor(dy0, o, 64)), dy1 = max(dy1, __shfl_xor(dy1, o, 64));
+      dx0 = min(dx0, __shfl_xor(dx0, o, 64)), dx1 = max(dx1, __shfl_xor(dx1, o, 64));
+    }
+    if (lane == 0) misc[0] = __popcll(mask), misc[2] = dy0, misc[3] = dy1, misc[4] = dx0, misc[5] = dx1;
+  }
+  __syncthreads();
+  const int nA = misc[0];  // 0 only for degenerate geometry (no tap ever reaches data): outputs are the bias alone
+
+  // ---- stage shape: CC channels x nA taps <= kBK rows --------------------------------------------------------------------
+  int CC = (LINEAR || nA <= 1) ? 32 : nA == 2 ? 16 : nA <= 4 ? 8 : 4;
+  while (CC > 4 && CC / 2 >= Cig) CC >>= 1;
+  // patch geometry (see bt_fused_fwd.h)
+  const int dymin = misc[2], dymax = misc[3], dxmin = misc[4], dxmax = misc[5];
+  const int t_R = pix ? 1 : a.Ho, t_Wt = pix ? 1 : a.Wo, t_NI = pix ? BM : BM / a.HoWo;
+  const int ps_h = (dymax == dymin) ? 1 : a.SH, gs_h = (dymax == dymin) ? a.SH : 1;
+  const int ps_w = (dxmax == dxmin) ? 1 : a.SW, gs_w = (dxmax == dxmin) ? a.SW : 1;
+  const int PHt = (t_R - 1) * ps_h + (dymax - dymin) + 1, PWt = (t_Wt - 1) * ps_w + (dxmax - dxmin) + 1;
+  const int PIMG = PHt * PWt, PCH = t_NI * PIMG;
+  if (!LINEAR)
+    while (CC > 4 && CC * PCH > X_WORDS) CC >>= 1;  // the host guaranteed 4 * PCH <= X_WORDS
+  const int lcc = 31 - __clz(CC);
+  const int KC = nA << lcc;  // K rows of every stage (a multiple of 4, <= 36)
+  const int NS = nA ? (Cig + CC - 1) / CC : 0;
+
+  // K-row table of the x tile, written once: consumers address  Xbuf[rowtab[k row] + colbase[lane]]
+  if (tid < KC) {
+    int off = tid * XS;
+    if (!LINEAR) {
+      const int4 e = taptab[tid >> lcc];
+      off = (tid & (CC - 1)) * PCH + (e.y - dymin) * PWt + (e.z - dxmin);
+    }
+    rowtab[tid] = off;
+  }
+
+  const float* const xs = a.x + (long long)s * a.x_sample_stride;
+  const float* const eps_w_s = INJ ? a.eps_w + (long long)s * a.w_elems : nullptr;
+  const float* const sin_s = (FLIP && INJ) ? a.sign_in + (long long)s * a.x_elems : nullptr;
+  const float* const sig_or_rho = a.sigma_w ? a.sigma_w : a.rho_w;
+  const bool have_sigma = a.sigma_w != nullptr;
+  // Buffer resources: 32-bit byte offsets against a scalar base, and the hardware range check returns 0 for an offset
+  // past the end -- a masked element is a load at kOOB, no select afterwards. (The host routes tensors of 2^29 elements
+  // or more to the general kernel, so valid offsets stay below kOOB.)
+  constexpr uint32_t kOOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t r_mu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mu_w), 0, (int)(a.w_elems * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sig_or_rho), 0, (int)(a.w_elems * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs), 0, (int)(a.x_elems * 4), 0x00020000);
+  auto ldf = [](const __amdgpu_buffer_rsrc_t& r, uint32_t byte_off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0)); };
+  auto ldf4 = [](const __amdgpu_buffer_rsrc_t& r, uint32_t byte_off) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0)); };
+
+  float* const buf0 = smem;
+  float* const buf1 = smem + BUF_WORDS;
+  float* const bias0 = smem;
+  float* const bias1 = smem + BN;
+  float* const osc = smem + 2 * BN;
+  float* const osh = smem + 3 * BN;
+  double kl_acc = 0.0;
+  const bool kl_block = a.do_kl && (int)blockIdx.x < a.kl_slices;
+
+  if (producer) {
+    // =================================================== PRODUCERS ===========================================================
+    // ---- per-thread state, decoded once ----
+    constexpr int UMAX = (BN * 9 + kProducers - 1) / kProducers;
+    const int ncq = CC >> 2, lncq = lcc - 2;
+    const int nunits = BN * ncq * nA;
+    uint32_t w_off[UMAX], e_off[UMAX];  // weight offset / draw index of (unit, channel chunk 0)
+    int l_off[UMAX], c_lim[UMAX];       // LDS offset of element 0; channels left in this quad
+    {
+      const uint32_t inv_na = nA > 1 ? (uint32_t)((0x100000000ull + (unsigned)nA - 1) / (unsigned)nA) : 0u;
+#pragma unroll
+      for (int i = 0; i < UMAX; ++i) {
+        const int u = ptid + kProducers * i;
+        const int uu = u < nunits ? u : 0;
+        const int tq = nA <= 1 ? uu : (int)__umulhi((uint32_t)uu, inv_na);
+        const int ai = uu - tq * (nA > 0 ? nA : 1);
+        const int cq = tq & (ncq - 1), r = tq >> lncq;
+        const int tap = LINEAR ? 0 : taptab[ai].w;
+        const int co_g = n0 + r;
+        const bool rv = u < nunits && co_g < a.Cog;
+        const uint32_t co = (uint32_t)(g * a.Cog + (rv ? co_g : 0));
+        w_off[i] = 4u * (co * (uint32_t)K + (uint32_t)(4 * cq * T + tap));  // bytes
+        e_off[i] = (co * (uint32_t)T + (uint32_t)tap) * (uint32_t)Cig + (uint32_t)(4 * cq);
+        l_off[i] = ((ai << lcc) + 4 * cq) * WS + r;
+        c_lim[i] = rv ? Cig - 4 * cq : (u < nunits ? 0 : -1);  // 0: slot exists but holds zeros; -1: no slot
+      }
+    }
+    const int wave_u0 = __builtin_amdgcn_readfirstlane(ptid & ~63);
+    // x patch: this thread owns plane positions ptid + 256*i (all channels of a stage)
+    constexpr int PPOS = (X_WORDS / 4 + kProducers - 1) / kProducers;
+    int p_off[PPOS];
+    if (!LINEAR) {
+      const uint32_t inv_pimg = (uint32_t)((0x100000000ull + (unsigned)PIMG - 1) / (unsigned)PIMG);
+      const uint32_t inv_pw = (uint32_t)((0x100000000ull + (unsigned)PWt - 1) / (unsigned)PWt);
+      const int y_lo = (pix ? (tile_p / a.Wo) * a.SH : 0) - a.PH + dymin, x_lo = (pix ? (tile_p % a.Wo) * a.SW : 0) - a.PW + dxmin;
+      const int b0 = pix ? m0 : m0 / a.HoWo;
+#pragma unroll
+      for (int i = 0; i < PPOS; ++i) {
+        const int pos = ptid + kProducers * i;
+        const int pp = pos < PCH ? pos : 0;
+        const int img = PIMG == 1 ? pp : (int)__umulhi((uint32_t)pp, inv_pimg);
+        const int rem = pp - img * PIMG;
+        const int yy = PWt == 1 ? rem : (int)__umulhi((uint32_t)rem, inv_pw);
+        const int xx = rem - yy * PWt;
+        const int b = b0 + img, y = y_lo + yy * gs_h, x = x_lo + xx * gs_w;
+        const bool ok = pos < PCH && b < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        p_off[i] = ok ? 4 * ((b * a.Ci + g * Cig) * a.HW + y * a.W + x) : (int)kOOB;  // bytes; halo / outside the tile: reads 0
+      }
+    }
+
+    auto produce = [&](auto LCCc, int st, float* buf) {
+      constexpr int LCC = decltype(LCCc)::value, CCs = 1 << LCC;
+      float* const Wt0 = buf;
+      float* const Wt1 = buf + W_WORDS;
+      float* const Xt0 = buf + NW * W_WORDS;
+      float* const Xt1 = Xt0 + X_WORDS;
+      const int c0 = st << LCC;
+      const uint32_t c0T = (uint32_t)(c0 * T);
+      // ---- loads: weights ----
+      static_assert(!INJ, "the fast flavour generates its draws on chip");
+      float mu[UMAX][4], rs[UMAX][4], ep[UMAX][4];
+#pragma unroll
+      for (int i = 0; i < UMAX; ++i) {
+        if (i == 0 || wave_u0 + kProducers * i < nunits) {  // wave-uniform
+          const uint32_t base = w_off[i] + 4u * c0T;
+          if constexpr (LINEAR) {
+            const uint32_t sb = (c0 < c_lim[i]) ? base : kOOB;
+            const float4 m4 = ldf4(r_mu, sb), r4 = ldf4(r_rs, sb);
+            mu[i][0] = m4.x, mu[i][1] = m4.y, mu[i][2] = m4.z, mu[i][3] = m4.w;
+            rs[i][0] = r4.x, rs[i][1] = r4.y, rs[i][2] = r4.z, rs[i][3] = r4.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t sb = (c0 + j < c_lim[i]) ? base + (uint32_t)(4 * j * T) : kOOB;
+              mu[i][j] = ldf(r_mu, sb);
+              rs[i][j] = ldf(r_rs, sb);
+            }
+          }
+        }
+      }
+      // ---- loads: activations ----
+      constexpr int RP = kProducers / 8;
+      constexpr int PC = LINEAR ? 1 : (X_WORDS / CCs + kProducers - 1) / kProducers;
+      constexpr int NXR = LINEAR ? ((BM + RP - 1) / RP) * 4 : PC * CCs;
+      float xv[NXR];
+      uint32_t xo[FLIP ? NXR : 1];
+      if constexpr (LINEAR) {
+        const int kq = ptid & 7, mr = ptid >> 3;
+#pragma unroll
+        for (int p = 0; p < (BM + RP - 1) / RP; ++p) {
+          const int rl = mr + p * RP;
+          const int m = m0 + rl, k = c0 + 4 * kq;
+          const uint32_t off = (uint32_t)m * (uint32_t)K + (uint32_t)k;
+          const bool in = rl < BM && m < a.M && k < K;
+          const float4 x4 = ldf4(r_x, in ? 4u * off : kOOB);
+          xv[4 * p] = x4.x, xv[4 * p + 1] = x4.y, xv[4 * p + 2] = x4.z, xv[4 * p + 3] = x4.w;
+          if constexpr (FLIP) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xo[4 * p + j] = off + j;
+          }
+        }
+      } else {
+        const int c0HWb = 4 * c0 * a.HW, HWb = 4 * a.HW;
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+          if (kProducers * i < PCH) {  // uniform
+#pragma unroll
+            for (int c = 0; c < CCs; ++c) {
+              const uint32_t off = (c0 + c < Cig) ? (uint32_t)(p_off[i] + c0HWb + c * HWb) : kOOB;  // channel test is uniform
+              xv[i * CCs + c] = ldf(r_x, off);
+              if constexpr (FLIP) xo[i * CCs + c] = off >> 2;
+            }
+          }
+        }
+      }
+      // ---- draws (no load feeds them) ----
+      if constexpr (!INJ) {
+#pragma unroll
+        for (int i = 0; i < UMAX; ++i)
+          if ((i == 0 || wave_u0 + kProducers * i < nunits) && c0 < c_lim[i]) philox_normal4(key_w, sample, (e_off[i] + (uint32_t)c0) >> 2, ep[i]);
+      }
+      // ---- sampled weights -> LDS ----
+#pragma unroll
+      for (int i = 0; i < UMAX; ++i) {
+        if ((i == 0 || wave_u0 + kProducers * i < nunits) && c_lim[i] >= 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool ev = c0 + j < c_lim[i];
+            const float sg = have_sigma ? rs[i][j] : softplus(rs[i][j]);
+            const float dl = __fmul_rn(sg, ev ? ep[i][j] : 0.f);
+            const float w0 = FLIP ? mu[i][j] : __fadd_rn(mu[i][j], dl);
+            Wt0[l_off[i] + j * WS] = ev ? w0 : 0.f;
+            if (FLIP) Wt1[l_off[i] + j * WS] = ev ? dl : 0.f;
+          }
+        }
+      }
+      // ---- activations -> LDS ----
+      if constexpr (LINEAR) {
+        const int kq = ptid & 7, mr = ptid >> 3;
+#pragma unroll
+        for (int p = 0; p < (BM + RP - 1) / RP; ++p) {
+          const int rl = mr + p * RP;
+          if (rl < BM) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int idx = (4 * kq + j) * XS + rl;
+              const float v = xv[4 * p + j];
+              Xt0[idx] = v;
+              if (FLIP) Xt1[idx] = __fmul_rn(v, hash_sign(skey_in, xo[4 * p + j]));
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+          const int pos = ptid + kProducers * i;
+          if (pos < PCH) {
+#pragma unroll
+            for (int c = 0; c < CCs; ++c) {
+              const float v = xv[i * CCs + c];
+              Xt0[c * PCH + pos] = v;
+              if (FLIP) Xt1[c * PCH + pos] = __fmul_rn(v, hash_sign(skey_in, xo[i * CCs + c]));
+            }
+          }
+        }
+      }
+    };
+
+    const bool stamp = a.dbg && blockIdx.x == 0 && tid == 256;
+    for (int st = 0; st <= NS; ++st) {  // NS + 1 barriers, like the consumer arm
+      if (stamp && st < 60) a.dbg[128 + 2 * st] = __builtin_amdgcn_s_memtime();
+      if (st < NS) {
+        float* const buf = (st & 1) ? buf1 : buf0;
+        switch (lcc) {
+          case 2: produce(std::integral_constant<int, 2>{}, st, buf); break;
+          case 3: produce(std::integral_constant<int, 3>{}, st, buf); break;
+          case 4: produce(std::integral_constant<int, 4>{}, st, buf); break;
+          default: produce(std::integral_constant<int, 5>{}, st, buf); break;
+        }
+      }
+      if (stamp && st < 60) a.dbg[128 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
+      __syncthreads();
+    }
+    // bias draw + output-stage constants of this workgroup's channels
+    if (ptid < BN) {
+      float b0 = 0.f, b1 = 0.f;
+      const int co_g = n0 + ptid;
+      if (a.mu_b && co_g < a.Cog) {
+        const int co = g * a.Cog + co_g;
+        float e;
+        if (INJ) {
+          e = a.eps_b[(long long)s * a.Co + co];
+        } else {
+          RngKey kb = key_w;
+          kb.layer_tensor = layer_tensor_word(a.layer_id, 1);
+          float z[4];
+          philox_normal4(kb, sample, (uint32_t)(co >> 2), z);
+          const int sel = co & 3;
+          e = sel == 0 ? z[0] : sel == 1 ? z[1] : sel == 2 ? z[2] : z[3];
+        }
+        const float dl = __fmul_rn(softplus(a.rho_b[co]), e);
+        b0 = FLIP ? a.mu_b[co] : __fadd_rn(a.mu_b[co], dl);
+        b1 = dl;
+      }
+      bias0[ptid] = b0;
+      if (FLIP) bias1[ptid] = b1;
+      const bool cv = a.ep_scale && co_g < a.Cog;
+      const int cs = cv ? g * a.Cog + co_g : 0;
+      const float sc = a.ep_scale ? a.ep_scale[cs] : 1.f, sh = a.ep_shift ? a.ep_shift[cs] : 0.f;
+      osc[ptid] = cv ? sc : 1.f;
+      osh[ptid] = cv ? sh : 0.f;
+    }
+    __syncthreads();
+  } else {
+    // =================================================== CONSUMERS ===========================================================
+    if (kl_block) {  // sweep this workgroup's slice of the weights for KL while the producers fill stage 0
+      long long chunk = (a.w_elems + a.kl_slices - 1) / a.kl_slices;
+      chunk = (chunk + 3) & ~3ll;
+      const long long lo = (long long)blockIdx.x * chunk;
+      const long long hi = (lo + chunk < a.w_elems) ? lo + chunk : a.w_elems;
+      const bool v4 = ((((uintptr_t)a.mu_w | (uintptr_t)a.rho_w | (uintptr_t)a.pmu_w | (uintptr_t)a.psig_w) & 15u) == 0);
+      long long i = lo + 4ll * ptid;
+      if (v4) {
+        for (; i + 3 < hi; i += 1024) {
+          const float4 m4 = *reinterpret_cast<const float4*>(a.mu_w + i), r4 = *reinterpret_cast<const float4*>(a.rho_w + i);
+          const float4 p4 = *reinterpret_cast<const float4*>(a.pmu_w + i), q4 = *reinterpret_cast<const float4*>(a.psig_w + i);
+          const float t0 = kl_term(m4.x, softplus(r4.x), p4.x, q4.x) + kl_term(m4.y, softplus(r4.y), p4.y, q4.y);
+          const float t1 = kl_term(m4.z, softplus(r4.z), p4.z, q4.z) + kl_term(m4.w, softplus(r4.w), p4.w, q4.w);
+          kl_acc += (double)t0 + (double)t1;
+        }
+      }
+      for (; i < hi; i += 1024)
+        for (int j = 0; j < 4; ++j)
+          if (i + j < hi) kl_acc += (double)kl_term(a.mu_w[i + j], softplus(a.rho_w[i + j]), a.pmu_w[i + j], a.psig_w[i + j]);
+    }
+    // LDS column base of this lane's output pixel per 32-wide column group
+    int colbase[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int ml = wm * WTM + j * 32 + li;
+      if (LINEAR) {
+        colbase[j] = ml;
+      } else {
+        const int img = pix ? ml : ml / a.HoWo, p = pix ? 0 : ml - img * a.HoWo;
+        const int ho = p / a.Wo, wo = p - ho * a.Wo;
+        colbase[j] = img * PIMG + ho * ps_h * PWt + wo * ps_w;
+      }
+    }
+    __syncthreads();  // stage 0 staged, rowtab written
+
+    // K-row offsets of this lane half, in registers for the whole kernel (the stage shape never changes)
+    int rowoff[kBK / 2];
+#pragma unroll
+    for (int q = 0; q < kBK / 2; ++q) rowoff[q] = (2 * q < KC) ? rowtab[2 * q + lh] : 0;
+    const int wrow = lh * WS + wn * WTN + li;
+
+    f32x16 acc[NW][TN][TM];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[w][i][j][r] = 0.f;
+
+    const bool stamp = a.dbg && blockIdx.x == 0 && tid == 0;
+    if (stamp) a.dbg[0] = __builtin_amdgcn_s_memtime();
+    for (int st = 0; st < NS; ++st) {
+      if (stamp && st < 60) a.dbg[2 + 2 * st] = __builtin_amdgcn_s_memtime();
+      const float* const buf = (st & 1) ? buf1 : buf0;
+      const float* const Wt0 = buf + wrow;
+      const float* const Wt1 = Wt0 + W_WORDS;
+      const float* const Xt0 = buf + NW * W_WORDS;
+      const float* const Xt1 = Xt0 + X_WORDS;
+      float af[2][NW][TN], bf[2][NW][TM];
+      auto load_frags = [&](auto slotc, auto qc) {
+        constexpr int slot = decltype(slotc)::value, q = decltype(qc)::value;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          af[slot][0][i] = Wt0[2 * q * WS + i * 32];
+          if (FLIP) af[slot][NW - 1][i] = Wt1[2 * q * WS + i * 32];
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          bf[slot][0][j] = Xt0[rowoff[q] + colbase[j]];
+          if (FLIP) bf[slot][NW - 1][j] = Xt1[rowoff[q] + colbase[j]];
+        }
+      };
+      auto mfmas = [&](auto slotc) {
+        constexpr int slot = decltype(slotc)::value;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+              acc[w][i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[slot][w][j], af[slot][w][i], acc[w][i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][w][i], bf[slot][w][j], acc[w][i][j], 0, 0, 0);
+      };
+      // 18 statically unrolled steps (2 K rows each), guarded by the stage's row count; fragments of step q+1 are
+      // fetched while the MFMAs of step q run
+      load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      auto step_pair = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;  // even step index
+        if (2 * q < KC) {                       // uniform; KC is a multiple of 4, so steps come in pairs
+          load_frags(std::integral_constant<int, 1>{}, std::integral_constant<int, q + 1>{});
+          mfmas(std::integral_constant<int, 0>{});
+          if constexpr (q + 2 < kBK / 2) {
+            if (2 * (q + 2) < KC) load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, q + 2>{});
+          }
+          mfmas(std::integral_constant<int, 1>{});
+        }
+      };
+      step_pair(std::integral_constant<int, 0>{});
+      step_pair(std::integral_constant<int, 2>{});
+      step_pair(std::integral_constant<int, 4>{});
+      step_pair(std::integral_constant<int, 6>{});
+      step_pair(std::integral_constant<int, 8>{});
+      step_pair(std::integral_constant<int, 10>{});
+      step_pair(std::integral_constant<int, 12>{});
+      step_pair(std::integral_constant<int, 14>{});
+      step_pair(std::integral_constant<int, 16>{});
+      if (stamp && st < 60) a.dbg[2 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
+      __syncthreads();
+    }
+    if (stamp) a.dbg[1] = __builtin_amdgcn_s_memtime();
+    __syncthreads();  // the producers have staged bias / output-stage constants
+
+    // ---- output stage + store ----
+    float* const out_s = a.out + (long long)s * a.out_elems;
+    const float* const sout_s = (FLIP && INJ) ? a.sign_out + (long long)s * a.out_elems : nullptr;
+    const float* const res_s = a.ep_res ? a.ep_res + (long long)s * a.ep_res_stride : nullptr;
+    const bool relu = a.ep_relu != 0;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      int b_col = 0, p_col = tile_p;
+      if (!TRANS) {
+        const int ml = m0 + wm * WTM + j * 32 + li;
+        if (pix) {
+          b_col = ml;
+        } else {
+          b_col = ml / a.HoWo;
+          p_col = ml - b_col * a.HoWo;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        uint32_t oi[16];
+        bool okv[16];
+        int col[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          int co_l, ml;
+          if (TRANS) {
+            co_l = wn * WTN + i * 32 + li;
+            ml = m0 + wm * WTM + j * 32 + row;
+            oi[r] = (uint32_t)((ml * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + tile_p);
+          } else {
+            co_l = wn * WTN + i * 32 + row;
+            ml = m0 + wm * WTM + j * 32 + li;
+            oi[r] = (uint32_t)((b_col * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + p_col);
+          }
+          okv[r] = n0 + co_l < a.Cog && ml < m_lim;
+          col[r] = co_l;
+          if (!okv[r]) oi[r] = 0u;
+        }
+        float rsd[16], so[FLIP ? 16 : 1];
+        if (res_s) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rsd[r] = res_s[oi[r]];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rsd[r] = 0.f;
+        }
+        if constexpr (FLIP) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) so[r] = INJ ? sout_s[oi[r]] : hash_sign(skey_out, oi[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = __fadd_rn(acc[0][i][j][r], bias0[col[r]]);
+          if constexpr (FLIP) v = __fadd_rn(v, __fmul_rn(__fadd_rn(acc[NW - 1][i][j][r], bias1[col[r]]), so[r]));
+          v = __fadd_rn(__fmul_rn(v, osc[col[r]]), osh[col[r]]);
+          v = __fadd_rn(v, rsd[r]);
+          v = (relu && v < 0.f) ? 0.f : v;
+          if (okv[r]) out_s[oi[r]] = v;
+        }
+      }
+    }
+  }
+
+  if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[126] = __builtin_amdgcn_s_memtime();
+  // ---- KL finish ----
+  if (!kl_block) return;
+  const double bsum = block_sum_all(kl_acc, red);
+  if (tid == 0) misc[1] = publish_and_ticket(a.slots, a.counter, (int)blockIdx.x, bsum, (unsigned)a.kl_slices) ? 1 : 0;
+  __syncthreads();
+  if (!misc[1]) return;
+  double bacc = 0.0;
+  if (a.mu_b)
+    for (int c = tid; c < a.Co; c += kThreads) bacc += (double)kl_term(a.mu_b[c], softplus(a.rho_b[c]), a.pmu_b[c], a.psig_b[c]);
+  const double bias_sum = block_sum_all(bacc, red);
+  if (tid == 0) {
+    double wsum = 0.0;
+    for (int i = 0; i < a.kl_slices; ++i) wsum += __hip_atomic_load(&a.slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float kl = (float)(wsum / (double)a.w_elems);
+    if (a.mu_b) kl += (float)(bias_sum / (double)a.Co);
+    a.kl_out[0] = kl;
+    __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+}  // namespace bt

@@ -49,6 +49,7 @@ struct FwdArgs {
   int B, Ci, H, W, Co, KH, KW, SH, SW, PH, PW, DH, DW, G;
   int Ho, Wo, HoWo, M, K, Cig, Cog, S, T, HW;
   int n_tiles, m_tiles, total_blocks;
+  int patch_ok;                   // host: tiles are whole images (or pixel-major), so the x operand can be staged as a patch
   int pixel_major, mt_per_pixel;  // m-tile = (one output pixel, BM images) instead of BM consecutive (b, ho, wo)
   int w_vec, x_vec;               // float4 paths allowed (taps == 1, K % 4 == 0, 16-B aligned bases)
   int do_kl, kl_slices;
@@ -70,7 +71,7 @@ __device__ __forceinline__ int xcd_remap(int orig, int n) {
 
 template <int BN, int BM, bool FLIP>
 constexpr int fused_lds_bytes() {
-  return (2 * (FLIP ? 2 : 1) * (kBK * (BN + 1) + kBK * (BM + 1)) + kMaxTaps * 4 + 24 + 8) * 4;
+  return (2 * (FLIP ? 2 : 1) * (kBK * (BN + 1) + kBK * (BM + 1)) + kMaxTaps * 4 + 24 + 8 + 80) * 4;
 }
 
 __device__ __forceinline__ double block_sum_all(double v, double* scratch) {  // 12 waves; result in thread 0
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // ONE LDS object
   int4* const taptab = reinterpret_cast<int4*>(smem + 2 * BUF_WORDS);
   double* const red = reinterpret_cast<double*>(smem + 2 * BUF_WORDS + kMaxTaps * 4);
-  int* const misc = reinterpret_cast<int*>(red + 12);  // [0] active tap count, [1] last-arriver flag
+  int* const misc = reinterpret_cast<int*>(red + 12);  // [0] active tap count, [1] last-arriver flag, [2..5] active-tap window
+  int* const rowtab = misc + 8;                        // [2][40]: LDS offset of every K row of a stage's x tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool producer = wave >= 4;
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
   // ---- active taps of this tile (wave 0: ballot compaction, ascending tap order) ---------------------------------
   if (wave == 0) {
     int base = 0;
+    int dy0 = 1 << 20, dy1 = -1, dx0 = 1 << 20, dx1 = -1;  // window of the active taps (input offsets kh*DH, kw*DW)
     for (int t0 = 0; t0 < T; t0 += 64) {
       const int t = t0 + lane;
       bool act = false;
@@ -164,8 +167,14 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
       const unsigned long long mask = __ballot(act);
       if (act) taptab[base + __popcll(mask & ((1ull << lane) - 1ull))] = e;
       base += __popcll(mask);
+      if (act) dy0 = min(dy0, e.y), dy1 = max(dy1, e.y), dx0 = min(dx0, e.z), dx1 = max(dx1, e.z);
     }
-    if (lane == 0) misc[0] = base;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      dy0 = min(dy0, __shfl_xor(dy0, o, 64)), dy1 = max(dy1, __shfl_xor(dy1, o, 64));
+      dx0 = min(dx0, __shfl_xor(dx0, o, 64)), dx1 = max(dx1, __shfl_xor(dx1, o, 64));
+    }
+    if (lane == 0) misc[0] = base, misc[2] = dy0, misc[3] = dy1, misc[4] = dx0, misc[5] = dx1;
   }
   __syncthreads();
   const int nA = misc[0];
@@ -185,6 +194,19 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
   const int lcc = 31 - __clz(CC);
   const int n_ach = (nA + NA - 1) / NA, n_cch = (Cig + CC - 1) / CC;
   const int NS = nA ? n_ach * n_cch : 0;
+
+  // ---- x operand as an LDS PATCH (conv, whole-image or pixel-major tiles): every input pixel the tile's outputs can
+  // touch is staged ONCE per channel (zero halo included) and the consumers address it as base(lane's output pixel) +
+  // offset(tap) + channel*plane -- instead of an im2col tile that re-gathers each pixel once per tap. 6-9x fewer load
+  // instructions for 3x3 kernels (the texture addresser needs 16 cycles per 64-lane dword load, coalesced or not).
+  const int dymin = misc[2], dymax = misc[3], dxmin = misc[4], dxmax = misc[5];
+  const int t_R = pix ? 1 : a.Ho, t_Wt = pix ? 1 : a.Wo;            // output rows / cols of one image inside the tile
+  const int t_NI = pix ? BM : BM / a.HoWo;                            // images per tile
+  const int ps_h = (dymax == dymin) ? 1 : a.SH, gs_h = (dymax == dymin) ? a.SH : 1;  // one row offset only: keep just the rows that are read
+  const int ps_w = (dxmax == dxmin) ? 1 : a.SW, gs_w = (dxmax == dxmin) ? a.SW : 1;
+  const int PHt = (t_R - 1) * ps_h + (dymax - dymin) + 1, PWt = (t_Wt - 1) * ps_w + (dxmax - dxmin) + 1;
+  const int PIMG = PHt * PWt, PCH = t_NI * PIMG;                      // plane of one image / of one channel
+  const bool use_patch = !LINEAR && a.patch_ok && nA > 0 && CC * PCH <= X_WORDS && PCH < 65536;
 
   // ---- producer-side constants ----------------------------------------------------------------------------------------
   const float* const xs = a.x + (long long)s * a.x_sample_stride;
@@ -255,6 +277,42 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
     }
   };
   if (!LINEAR && producer && n_ach == 1) setup_taps(0, nA);
+  // patch fill: this thread owns plane positions pos = ptid + 256*i (all channels of the stage)
+  constexpr int PPOS = (X_WORDS / 4 + kProducers - 1) / kProducers;
+  int p_off[PPOS];
+  unsigned p_ok = 0;
+  if (use_patch && producer) {
+    const uint32_t inv_pimg = (uint32_t)((0x100000000ull + (unsigned)PIMG - 1) / (unsigned)PIMG);
+    const uint32_t inv_pw = (uint32_t)((0x100000000ull + (unsigned)PWt - 1) / (unsigned)PWt);
+    const int y_lo = (pix ? (tile_p / a.Wo) * a.SH : 0) - a.PH + dymin, x_lo = (pix ? (tile_p % a.Wo) * a.SW : 0) - a.PW + dxmin;
+    const int b0 = pix ? m0 : m0 / a.HoWo;
+#pragma unroll
+    for (int i = 0; i < PPOS; ++i) {
+      const int pos = ptid + kProducers * i;
+      const int pp = pos < PCH ? pos : 0;
+      const int img = PIMG == 1 ? pp : (int)__umulhi((uint32_t)pp, inv_pimg);
+      const int rem = pp - img * PIMG;
+      const int yy = PWt == 1 ? rem : (int)__umulhi((uint32_t)rem, inv_pw);
+      const int xx = rem - yy * PWt;
+      const int b = b0 + img, y = y_lo + yy * gs_h, x = x_lo + xx * gs_w;
+      const bool ok = pos < PCH && b < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+      p_off[i] = ok ? (b * a.Ci + g * Cig) * a.HW + y * a.W + x : 0;
+      if (ok) p_ok |= 1u << i;
+    }
+  }
+  // consumers: LDS column base of this lane's output pixel, per 32-wide tile column group
+  int colbase[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int ml = wm * WTM + j * 32 + li;
+    if (use_patch) {
+      const int img = pix ? ml : ml / a.HoWo, p = pix ? 0 : ml - img * a.HoWo;
+      const int ho = p / a.Wo, wo = p - ho * a.Wo;
+      colbase[j] = img * PIMG + ho * ps_h * PWt + wo * ps_w;
+    } else {
+      colbase[j] = ml;
+    }
+  }
   const float* const sig_or_rho = a.sigma_w ? a.sigma_w : a.rho_w;
   const bool have_sigma = a.sigma_w != nullptr;
 
@@ -275,6 +333,7 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
     const bool pst = a.dbg && blockIdx.x == 0 && tid == 256 && st == 3;
     if (pst) a.dbg[250] = __builtin_amdgcn_s_memtime();
     if (!LINEAR && n_ach > 1) setup_taps(a0, na_s);
+    if (pst) a.dbg[239] = __builtin_amdgcn_s_memtime();
     // -------- weights: loads -----------------------------------------------------------------------------------------------
     float mu[UMAX][4], rs[UMAX][4], ep[UMAX][4];
     uint32_t ue0[UMAX];
@@ -314,12 +373,30 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
         }
       }
     }
+    if (pst) a.dbg[240] = __builtin_amdgcn_s_memtime();
+    // -------- K-row table of this stage's x tile (consumers: address = rowtab[k row] + colbase[lane]) ------------------------
+    {
+      int* const rt = rowtab + (st & 1) * 40;
+      const int KCs = na_s << LCC;
+      if (ptid < KCs) {
+        int off = ptid * XS;  // im2col / Linear tile: row-major [k][m]
+        if (use_patch) {
+          const int4 e = taptab[a0 + (ptid >> LCC)];
+          off = (ptid & (CCs - 1)) * PCH + (e.y - dymin) * PWt + (e.z - dxmin);
+        }
+        rt[ptid] = off;
+      }
+    }
+    if (pst) a.dbg[241] = __builtin_amdgcn_s_memtime();
     // -------- activations: loads --------------------------------------------------------------------------------------------
     constexpr bool FASTX = !LINEAR && (NG <= 4);                   // static (tap, channel) nest; NG <= 4 <= CC
     constexpr int CPT = FASTX ? CCs / NG : 1;                      // channels per (thread, tap)
     constexpr int TPS = FASTX ? kBK / CCs : 1;                     // tap slots of a stage
     constexpr int RP = kProducers / 8;                             // Linear: tile rows per pass
-    constexpr int NXR = LINEAR ? ((BM + RP - 1) / RP) * 4 : (FASTX ? TPS * CPT : (kBK + NG - 1) / NG);
+    constexpr int NXR_G = LINEAR ? ((BM + RP - 1) / RP) * 4 : (FASTX ? TPS * CPT : (kBK + NG - 1) / NG);
+    constexpr int NXR_P = LINEAR ? 1 : ((X_WORDS / CCs + kProducers - 1) / kProducers) * CCs;
+    constexpr int NXR = NXR_G > NXR_P ? NXR_G : NXR_P;
+    static_assert(NXR <= 64, "element mask is 64 bits");
     float xv[NXR], xs_[FLIP ? NXR : 1];
     uint32_t xo[FLIP ? NXR : 1];
     unsigned long long xok = 0;  // bit q: element q is real data (else zero padding / outside the tile)
@@ -341,6 +418,24 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
           if constexpr (INJ) {
             const float4 s4 = *reinterpret_cast<const float4*>(sin_s + so);
             xs_[4 * p] = s4.x, xs_[4 * p + 1] = s4.y, xs_[4 * p + 2] = s4.z, xs_[4 * p + 3] = s4.w;
+          }
+        }
+      }
+    } else if (use_patch) {
+      constexpr int PC = (X_WORDS / CCs + kProducers - 1) / kProducers;  // plane positions per thread at this channel count
+#pragma unroll
+      for (int i = 0; i < PC; ++i) {
+        if (kProducers * i < PCH) {  // uniform: small planes need few passes
+#pragma unroll
+          for (int c = 0; c < CCs; ++c) {
+            const bool ok = ((p_ok >> i) & 1u) && (c0 + c < Cig);
+            if (ok) xok |= 1ull << (i * CCs + c);
+            const uint32_t off = ok ? (uint32_t)(p_off[i] + (c0 + c) * a.HW) : 0u;
+            xv[i * CCs + c] = xs[off];
+            if constexpr (FLIP) {
+              xo[i * CCs + c] = off;
+              if constexpr (INJ) xs_[i * CCs + c] = sin_s[off];
+            }
           }
         }
       }
@@ -433,6 +528,20 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
           }
         }
       }
+    } else if (use_patch) {
+      constexpr int PC = (X_WORDS / CCs + kProducers - 1) / kProducers;
+#pragma unroll
+      for (int i = 0; i < PC; ++i) {
+        const int pos = ptid + kProducers * i;
+        if (pos < PCH) {
+#pragma unroll
+          for (int c = 0; c < CCs; ++c) {
+            const float v = ((xok >> (i * CCs + c)) & 1ull) ? xv[i * CCs + c] : 0.f;
+            Xt0[c * PCH + pos] = v;
+            if (FLIP) Xt1[c * PCH + pos] = __fmul_rn(v, INJ ? xs_[i * CCs + c] : hash_sign(skey_in, xo[i * CCs + c]));
+          }
+        }
+      }
     } else if constexpr (FASTX) {
 #pragma unroll
       for (int t = 0; t < TPS; ++t)
@@ -469,11 +578,12 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
   auto consume = [&](f32x16 (&acc)[NW][TN][TM], int st, const float* buf) {
     const float* const Wt0 = buf + wn * WTN + li;
     const float* const Wt1 = Wt0 + W_WORDS;
-    const float* const Xt0 = buf + NW * W_WORDS + wm * WTM + li;
+    const float* const Xt0 = buf + NW * W_WORDS;
     const float* const Xt1 = Xt0 + X_WORDS;
+    const int* const rt = rowtab + (st & 1) * 40 + lh;
     const int cch = st / n_ach, ach = st - cch * n_ach;
     const int na_s = (nA - ach * NA) < NA ? (nA - ach * NA) : NA;
-    const int KC = na_s << lcc;  // even (CC >= 4)
+    const int KC = na_s << lcc;  // a multiple of 4 (CC >= 4)
     // fragments of step kk + 2 are read from LDS while the MFMAs of step kk execute
     float af[2][NW][TN], bf[2][NW][TM];
     auto load_frags = [&](auto slotc, int kk) {
@@ -483,10 +593,11 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
         af[slot][0][i] = Wt0[(kk + lh) * WS + i * 32];
         if (FLIP) af[slot][NW - 1][i] = Wt1[(kk + lh) * WS + i * 32];
       }
+      const int ro = rt[kk];
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        bf[slot][0][j] = Xt0[(kk + lh) * XS + j * 32];
-        if (FLIP) bf[slot][NW - 1][j] = Xt1[(kk + lh) * XS + j * 32];
+        bf[slot][0][j] = Xt0[ro + colbase[j]];
+        if (FLIP) bf[slot][NW - 1][j] = Xt1[ro + colbase[j]];
       }
     };
     auto mfmas = [&](auto slotc) {
