@@ -25,7 +25,7 @@ class bt_rng(C.Structure):
 
 
 class bt_params(C.Structure):
-    _fields_ = [(n, _vp) for n in ("mu_w", "rho_w", "mu_b", "rho_b", "prior_mu_w", "prior_sigma_w", "prior_mu_b", "prior_sigma_b", "sigma_w")]
+    _fields_ = [(n, _vp) for n in ("mu_w", "rho_w", "mu_b", "rho_b", "prior_mu_w", "prior_sigma_w", "prior_mu_b", "prior_sigma_b", "mu_packed", "sigma_packed")]
 
 
 class bt_draws(C.Structure):
@@ -54,7 +54,7 @@ _PROTOS = {
     "bt_flipout_conv2d_fwd": (C.c_int, [C.POINTER(bt_conv2d_geom), C.c_int32] + _FWD_TAIL),
     "bt_kl_normal": (C.c_int, [C.c_int32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int64),
                                C.POINTER(C.c_int32), C.c_uint32, _vp, _vp, C.c_size_t, _vp]),
-    "bt_softplus": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "bt_pack_params": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp]),
     "bt_rng_normal_fill": (C.c_int, [C.POINTER(bt_rng), C.c_uint32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]),
     "bt_rng_sign_fill": (C.c_int, [C.POINTER(bt_rng), C.c_uint32, C.c_int32, C.c_int64, _vp, _vp]),
     "bt_rng_philox_raw": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -48,7 +48,8 @@ static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const flo
   FwdArgs zero = {}; a = zero;
   a.x = x, a.mu_w = p->mu_w, a.rho_w = p->rho_w, a.mu_b = p->mu_b, a.rho_b = p->rho_b;
   a.pmu_w = p->prior_mu_w, a.psig_w = p->prior_sigma_w, a.pmu_b = p->prior_mu_b, a.psig_b = p->prior_sigma_b;
-  a.sigma_w = p->sigma_w;
+  if ((p->mu_packed == nullptr) != (p->sigma_packed == nullptr)) return bad("mu_packed and sigma_packed must both be given or both be NULL");
+  a.mu_pk = p->mu_packed, a.sig_pk = p->sigma_packed;
   a.eps_w = d->eps_w, a.eps_b = d->eps_b, a.sign_in = d->sign_in, a.sign_out = d->sign_out;
   a.out = out, a.kl_out = kl_out;
   a.slots = kl_out ? ws_slots(ws) : nullptr;
@@ -71,7 +72,7 @@ static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const flo
   // pixel-major tiles prune padding taps per output pixel; worth it when images are tiny (2x2 outputs: 4 of 9 taps)
   a.pixel_major = (!linear && a.HoWo >= 2 && a.HoWo <= 4 && (g.ph > 0 || g.pw > 0)) ? 1 : 0;
   a.x_sample_stride = x_sample_stride;
-  a.w_vec = linear && ((K & 3) == 0) && al16(p->mu_w) && al16(p->rho_w) && (!p->sigma_w || al16(p->sigma_w)) && (!d->eps_w || al16(d->eps_w));
+  a.w_vec = linear && ((K & 3) == 0) && al16(p->mu_w) && al16(p->rho_w) && (!d->eps_w || al16(d->eps_w));
   a.x_vec = linear && ((K & 3) == 0) && al16(x) && ((x_sample_stride & 3) == 0) && (!d->sign_in || al16(d->sign_in));
   a.do_kl = kl_out != nullptr;
   a.seed_lo = (uint32_t)d->rng.seed, a.seed_hi = (uint32_t)(d->rng.seed >> 32);

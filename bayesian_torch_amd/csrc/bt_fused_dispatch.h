@@ -11,7 +11,7 @@ namespace bt {
 template <int BM, bool LINEAR>
 static bool fast_ok(const FwdArgs& a) {
   static const bool forced_off = getenv("BT_FORCE_GENERIC") != nullptr;  // A/B hook for tests and benchmarks
-  if (forced_off || a.T > 9 || (a.Cig & 3) || a.w_elems >= (1ll << 29) || a.x_elems >= (1ll << 29)) return false;
+  if (forced_off || !a.mu_pk || (((uintptr_t)a.mu_pk | (uintptr_t)a.sig_pk) & 15u) || a.T > kMaxTaps / 2 || a.w_elems >= (1ll << 29) || a.x_elems >= (1ll << 29)) return false;
   if (LINEAR) return true;  // the LINEAR flavour is only dispatched when its float4 conditions hold
   if (!(a.pixel_major || (a.HoWo <= BM && BM % a.HoWo == 0))) return false;
   const int NI = a.pixel_major ? BM : BM / a.HoWo, R = a.pixel_major ? 1 : a.Ho, Wt = a.pixel_major ? 1 : a.Wo;

@@ -2,12 +2,12 @@
 //
 // Same algorithm, specialised to what the convolution / linear layers of real models look like so that the producers'
 // steady-state loop is a handful of instructions per element on state that lives in VGPRs:
-//   * kh*kw <= 9  -> every active tap fits one K-stage: a stage is (CC channels) x (all active taps), identical for every
-//     channel chunk, so the unit decode, the tap of each unit, the patch geometry and the K-row table are computed ONCE;
-//   * Ci/groups % 4 == 0 -> the 4 channels of a weight unit are exactly one Philox block;
+//   * the stage shape (CC channels x NA active taps) is fixed, so the unit decode, the patch geometry and -- when all
+//     active taps fit one stage (kh*kw <= 9) -- each unit's tap and the K-row table are computed ONCE; larger kernels
+//     (7x7 stems) walk the taps in chunks of 9 over the same staged patch;
 //   * convolutions stage x as an LDS patch (each input pixel loaded once per stage, zero halo included), tiles are whole
 //     images or pixel-major; Linear stages its row-major tile with float4 loads.
-// Everything else (7x7 stems, odd channel counts, tiles that split images, > 2^16-element planes) runs the general kernel.
+// Everything else (tiles that split images, planes that do not fit, injected draws, unaligned Linear) runs the general kernel.
 #pragma once
 #include "bt_fused_fwd.h"
 
@@ -96,8 +96,11 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
   const int nA = misc[0];  // 0 only for degenerate geometry (no tap ever reaches data): outputs are the bias alone
 
   // ---- stage shape: CC channels x nA taps <= kBK rows --------------------------------------------------------------------
+  const int NA = nA < 9 ? nA : 9;                       // taps per stage
+  const int n_ach = nA ? (nA + NA - 1) / NA : 1;        // tap chunks (1 unless kh*kw > 9)
   int CC = (LINEAR || nA <= 1) ? 32 : nA == 2 ? 16 : nA <= 4 ? 8 : 4;
   while (CC > 4 && CC / 2 >= Cig) CC >>= 1;
+  const int Cig4 = (Cig + 3) & ~3;
   // patch geometry (see bt_fused_fwd.h)
   const int dymin = misc[2], dymax = misc[3], dxmin = misc[4], dxmax = misc[5];
   const int t_R = pix ? 1 : a.Ho, t_Wt = pix ? 1 : a.Wo, t_NI = pix ? BM : BM / a.HoWo;
@@ -108,36 +111,40 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
   if (!LINEAR)
     while (CC > 4 && CC * PCH > X_WORDS) CC >>= 1;  // the host guaranteed 4 * PCH <= X_WORDS
   const int lcc = 31 - __clz(CC);
-  const int KC = nA << lcc;  // K rows of every stage (a multiple of 4, <= 36)
-  const int NS = nA ? (Cig + CC - 1) / CC : 0;
+  const int KC = NA << lcc;  // K rows of a full stage (a multiple of 4, <= 36)
+  const int NS = nA ? n_ach * ((Cig + CC - 1) / CC) : 0;
 
-  // K-row table of the x tile, written once: consumers address  Xbuf[rowtab[k row] + colbase[lane]]
-  if (tid < KC) {
-    int off = tid * XS;
-    if (!LINEAR) {
-      const int4 e = taptab[tid >> lcc];
-      off = (tid & (CC - 1)) * PCH + (e.y - dymin) * PWt + (e.z - dxmin);
+  // K-row table of the x tile: consumers address  Xbuf[rowtab[k row] + colbase[lane]]. One table when every stage has
+  // the same taps (n_ach == 1), else rewritten per stage by the producers.
+  auto write_rowtab = [&](int slot, int a0, int rows, int t) {
+    if (t < rows) {
+      int off = t * XS;
+      if (!LINEAR) {
+        const int4 e = taptab[a0 + (t >> lcc)];
+        off = (t & (CC - 1)) * PCH + (e.y - dymin) * PWt + (e.z - dxmin);
+      }
+      rowtab[slot * 40 + t] = off;
     }
-    rowtab[tid] = off;
-  }
+  };
+  if (n_ach == 1) write_rowtab(0, 0, KC, tid);
 
   const float* const xs = a.x + (long long)s * a.x_sample_stride;
   const float* const eps_w_s = INJ ? a.eps_w + (long long)s * a.w_elems : nullptr;
   const float* const sin_s = (FLIP && INJ) ? a.sign_in + (long long)s * a.x_elems : nullptr;
-  const float* const sig_or_rho = a.sigma_w ? a.sigma_w : a.rho_w;
-  const bool have_sigma = a.sigma_w != nullptr;
+
   // Buffer resources: 32-bit byte offsets against a scalar base, and the hardware range check returns 0 for an offset
   // past the end -- a masked element is a load at kOOB, no select afterwards. (The host routes tensors of 2^29 elements
   // or more to the general kernel, so valid offsets stay below kOOB.)
   constexpr uint32_t kOOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t r_mu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mu_w), 0, (int)(a.w_elems * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sig_or_rho), 0, (int)(a.w_elems * 4), 0x00020000);
+  const int pk_bytes = a.Co * T * Cig4 * 4;  // packed parameter tensors [Co][T][Cig4]
+  const __amdgpu_buffer_rsrc_t r_mu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mu_pk), 0, pk_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sig_pk), 0, pk_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs), 0, (int)(a.x_elems * 4), 0x00020000);
   auto ldf = [](const __amdgpu_buffer_rsrc_t& r, uint32_t byte_off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0)); };
   auto ldf4 = [](const __amdgpu_buffer_rsrc_t& r, uint32_t byte_off) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0)); };
 
-  float* const buf0 = smem;
-  float* const buf1 = smem + BUF_WORDS;
+  float* const wbuf = smem;                       // [2][NW][W_WORDS]  by stage parity
+  float* const xbuf = smem + 2 * NW * W_WORDS;    // [2][NW][X_WORDS]  by channel-chunk parity (tap chunks share the patch)
   float* const bias0 = smem;
   float* const bias1 = smem + BN;
   float* const osc = smem + 2 * BN;
@@ -150,26 +157,26 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
     // ---- per-thread state, decoded once ----
     constexpr int UMAX = (BN * 9 + kProducers - 1) / kProducers;
     const int ncq = CC >> 2, lncq = lcc - 2;
-    const int nunits = BN * ncq * nA;
-    uint32_t w_off[UMAX], e_off[UMAX];  // weight offset / draw index of (unit, channel chunk 0)
-    int l_off[UMAX], c_lim[UMAX];       // LDS offset of element 0; channels left in this quad
+    const int nunits = BN * ncq * NA;
+    uint32_t e_off[UMAX];  // draw index of (unit, channel chunk 0[, tap when hoisted]) == element offset in the packed tensors
+    int l_off[UMAX], c_lim[UMAX], u_ai[UMAX];  // LDS offset of element 0; channels left in this quad; tap slot
     {
-      const uint32_t inv_na = nA > 1 ? (uint32_t)((0x100000000ull + (unsigned)nA - 1) / (unsigned)nA) : 0u;
+      const uint32_t inv_na = NA > 1 ? (uint32_t)((0x100000000ull + (unsigned)NA - 1) / (unsigned)NA) : 0u;
 #pragma unroll
       for (int i = 0; i < UMAX; ++i) {
         const int u = ptid + kProducers * i;
         const int uu = u < nunits ? u : 0;
-        const int tq = nA <= 1 ? uu : (int)__umulhi((uint32_t)uu, inv_na);
-        const int ai = uu - tq * (nA > 0 ? nA : 1);
+        const int tq = NA <= 1 ? uu : (int)__umulhi((uint32_t)uu, inv_na);
+        const int ai = uu - tq * (NA > 0 ? NA : 1);
         const int cq = tq & (ncq - 1), r = tq >> lncq;
-        const int tap = LINEAR ? 0 : taptab[ai].w;
+        const int tap = (LINEAR || n_ach > 1) ? 0 : taptab[ai].w;  // several tap chunks: the tap is added per stage
+        u_ai[i] = ai;
         const int co_g = n0 + r;
         const bool rv = u < nunits && co_g < a.Cog;
         const uint32_t co = (uint32_t)(g * a.Cog + (rv ? co_g : 0));
-        w_off[i] = 4u * (co * (uint32_t)K + (uint32_t)(4 * cq * T + tap));  // bytes
-        e_off[i] = (co * (uint32_t)T + (uint32_t)tap) * (uint32_t)Cig + (uint32_t)(4 * cq);
+        e_off[i] = (co * (uint32_t)T + (uint32_t)tap) * (uint32_t)Cig4 + (uint32_t)(4 * cq);
         l_off[i] = ((ai << lcc) + 4 * cq) * WS + r;
-        c_lim[i] = rv ? Cig - 4 * cq : (u < nunits ? 0 : -1);  // 0: slot exists but holds zeros; -1: no slot
+        c_lim[i] = rv ? Cig4 - 4 * cq : (u < nunits ? 0 : -1);  // 0: slot exists but holds zeros; -1: no slot
       }
     }
     const int wave_u0 = __builtin_amdgcn_readfirstlane(ptid & ~63);
@@ -195,34 +202,37 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
       }
     }
 
-    auto produce = [&](auto LCCc, int st, float* buf) {
+    auto produce = [&](auto LCCc, int st) {
       constexpr int LCC = decltype(LCCc)::value, CCs = 1 << LCC;
-      float* const Wt0 = buf;
-      float* const Wt1 = buf + W_WORDS;
-      float* const Xt0 = buf + NW * W_WORDS;
+      const int cch = n_ach == 1 ? st : st / n_ach, ach = st - cch * n_ach;
+      const int a0 = ach * NA, na_s = (nA - a0) < NA ? (nA - a0) : NA;
+      float* const Wt0 = wbuf + (st & 1) * NW * W_WORDS;
+      float* const Wt1 = Wt0 + W_WORDS;
+      float* const Xt0 = xbuf + (cch & 1) * NW * X_WORDS;
       float* const Xt1 = Xt0 + X_WORDS;
-      const int c0 = st << LCC;
-      const uint32_t c0T = (uint32_t)(c0 * T);
+      const int c0 = cch << LCC;
+      uint32_t tap_e[UMAX];  // per-stage tap part of the draw index (zero when the tap is hoisted)
+#pragma unroll
+      for (int i = 0; i < UMAX; ++i) tap_e[i] = 0;
+      if (n_ach > 1) {
+#pragma unroll
+        for (int i = 0; i < UMAX; ++i) {
+          const int tap = taptab[a0 + (u_ai[i] < na_s ? u_ai[i] : 0)].w;
+          tap_e[i] = (uint32_t)(tap * Cig4);
+        }
+        write_rowtab(st & 1, a0, na_s << LCC, ptid);
+      }
       // ---- loads: weights ----
       static_assert(!INJ, "the fast flavour generates its draws on chip");
       float mu[UMAX][4], rs[UMAX][4], ep[UMAX][4];
 #pragma unroll
       for (int i = 0; i < UMAX; ++i) {
         if (i == 0 || wave_u0 + kProducers * i < nunits) {  // wave-uniform
-          const uint32_t base = w_off[i] + 4u * c0T;
-          if constexpr (LINEAR) {
-            const uint32_t sb = (c0 < c_lim[i]) ? base : kOOB;
-            const float4 m4 = ldf4(r_mu, sb), r4 = ldf4(r_rs, sb);
-            mu[i][0] = m4.x, mu[i][1] = m4.y, mu[i][2] = m4.z, mu[i][3] = m4.w;
-            rs[i][0] = r4.x, rs[i][1] = r4.y, rs[i][2] = r4.z, rs[i][3] = r4.w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const uint32_t sb = (c0 + j < c_lim[i]) ? base + (uint32_t)(4 * j * T) : kOOB;
-              mu[i][j] = ldf(r_mu, sb);
-              rs[i][j] = ldf(r_rs, sb);
-            }
-          }
+          // one 16-byte load per tensor: the packed layout puts the unit's 4 channels at the offset of its draw index
+          const uint32_t sb = (u_ai[i] < na_s && c0 < c_lim[i]) ? 4u * (e_off[i] + tap_e[i] + (uint32_t)c0) : kOOB;
+          const float4 m4 = ldf4(r_mu, sb), r4 = ldf4(r_rs, sb);
+          mu[i][0] = m4.x, mu[i][1] = m4.y, mu[i][2] = m4.z, mu[i][3] = m4.w;
+          rs[i][0] = r4.x, rs[i][1] = r4.y, rs[i][2] = r4.z, rs[i][3] = r4.w;
         }
       }
       // ---- loads: activations ----
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
             for (int j = 0; j < 4; ++j) xo[4 * p + j] = off + j;
           }
         }
-      } else {
+      } else if (ach == 0) {  // later tap chunks reuse the staged patch
         const int c0HWb = 4 * c0 * a.HW, HWb = 4 * a.HW;
 #pragma unroll
         for (int i = 0; i < PC; ++i) {
@@ -264,20 +274,19 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
       if constexpr (!INJ) {
 #pragma unroll
         for (int i = 0; i < UMAX; ++i)
-          if ((i == 0 || wave_u0 + kProducers * i < nunits) && c0 < c_lim[i]) philox_normal4(key_w, sample, (e_off[i] + (uint32_t)c0) >> 2, ep[i]);
+          if ((i == 0 || wave_u0 + kProducers * i < nunits) && c0 < c_lim[i] && u_ai[i] < na_s)
+            philox_normal4(key_w, sample, (e_off[i] + tap_e[i] + (uint32_t)c0) >> 2, ep[i]);
       }
       // ---- sampled weights -> LDS ----
 #pragma unroll
       for (int i = 0; i < UMAX; ++i) {
-        if ((i == 0 || wave_u0 + kProducers * i < nunits) && c_lim[i] >= 0) {
+        if ((i == 0 || wave_u0 + kProducers * i < nunits) && c_lim[i] >= 0 && u_ai[i] < na_s) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const bool ev = c0 + j < c_lim[i];
-            const float sg = have_sigma ? rs[i][j] : softplus(rs[i][j]);
-            const float dl = __fmul_rn(sg, ev ? ep[i][j] : 0.f);
-            const float w0 = FLIP ? mu[i][j] : __fadd_rn(mu[i][j], dl);
-            Wt0[l_off[i] + j * WS] = ev ? w0 : 0.f;
-            if (FLIP) Wt1[l_off[i] + j * WS] = ev ? dl : 0.f;
+            // masked units loaded zeros (mu = sigma = 0) and padded channels are zero in the pack: no select needed
+            const float dl = __fmul_rn(rs[i][j], (c0 < c_lim[i]) ? ep[i][j] : 0.f);
+            Wt0[l_off[i] + j * WS] = FLIP ? mu[i][j] : __fadd_rn(mu[i][j], dl);
+            if (FLIP) Wt1[l_off[i] + j * WS] = dl;
           }
         }
       }
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
             }
           }
         }
-      } else {
+      } else if (ach == 0) {
 #pragma unroll
         for (int i = 0; i < PC; ++i) {
           const int pos = ptid + kProducers * i;
@@ -317,12 +326,11 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
     for (int st = 0; st <= NS; ++st) {  // NS + 1 barriers, like the consumer arm
       if (stamp && st < 60) a.dbg[128 + 2 * st] = __builtin_amdgcn_s_memtime();
       if (st < NS) {
-        float* const buf = (st & 1) ? buf1 : buf0;
         switch (lcc) {
-          case 2: produce(std::integral_constant<int, 2>{}, st, buf); break;
-          case 3: produce(std::integral_constant<int, 3>{}, st, buf); break;
-          case 4: produce(std::integral_constant<int, 4>{}, st, buf); break;
-          default: produce(std::integral_constant<int, 5>{}, st, buf); break;
+          case 2: produce(std::integral_constant<int, 2>{}, st); break;
+          case 3: produce(std::integral_constant<int, 3>{}, st); break;
+          case 4: produce(std::integral_constant<int, 4>{}, st); break;
+          default: produce(std::integral_constant<int, 5>{}, st); break;
         }
       }
       if (stamp && st < 60) a.dbg[128 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
     // K-row offsets of this lane half, in registers for the whole kernel (the stage shape never changes)
     int rowoff[kBK / 2];
 #pragma unroll
-    for (int q = 0; q < kBK / 2; ++q) rowoff[q] = (2 * q < KC) ? rowtab[2 * q + lh] : 0;
+    for (int q = 0; q < kBK / 2; ++q) rowoff[q] = (n_ach == 1 && 2 * q < KC) ? rowtab[2 * q + lh] : 0;
     const int wrow = lh * WS + wn * WTN + li;
 
     f32x16 acc[NW][TN][TM];
@@ -415,10 +423,17 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
     if (stamp) a.dbg[0] = __builtin_amdgcn_s_memtime();
     for (int st = 0; st < NS; ++st) {
       if (stamp && st < 60) a.dbg[2 + 2 * st] = __builtin_amdgcn_s_memtime();
-      const float* const buf = (st & 1) ? buf1 : buf0;
-      const float* const Wt0 = buf + wrow;
+      const int cch = n_ach == 1 ? st : st / n_ach;
+      int KCs = KC;  // K rows of this stage
+      if (n_ach > 1) {
+        const int ach = st - cch * n_ach;
+        KCs = ((nA - ach * NA) < NA ? (nA - ach * NA) : NA) << lcc;
+#pragma unroll
+        for (int q = 0; q < kBK / 2; ++q) rowoff[q] = (2 * q < KCs) ? rowtab[(st & 1) * 40 + 2 * q + lh] : 0;
+      }
+      const float* const Wt0 = wbuf + (st & 1) * NW * W_WORDS + wrow;
       const float* const Wt1 = Wt0 + W_WORDS;
-      const float* const Xt0 = buf + NW * W_WORDS;
+      const float* const Xt0 = xbuf + (cch & 1) * NW * X_WORDS;
       const float* const Xt1 = Xt0 + X_WORDS;
       float af[2][NW][TN], bf[2][NW][TM];
       auto load_frags = [&](auto slotc, auto qc) {
@@ -450,11 +465,11 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
       load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
       auto step_pair = [&](auto qc) {
         constexpr int q = decltype(qc)::value;  // even step index
-        if (2 * q < KC) {                       // uniform; KC is a multiple of 4, so steps come in pairs
+        if (2 * q < KCs) {                      // uniform; the row count is a multiple of 4, so steps come in pairs
           load_frags(std::integral_constant<int, 1>{}, std::integral_constant<int, q + 1>{});
           mfmas(std::integral_constant<int, 0>{});
           if constexpr (q + 2 < kBK / 2) {
-            if (2 * (q + 2) < KC) load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, q + 2>{});
+            if (2 * (q + 2) < KCs) load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, q + 2>{});
           }
           mfmas(std::integral_constant<int, 1>{});
         }

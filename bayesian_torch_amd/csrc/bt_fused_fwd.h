@@ -39,7 +39,7 @@ constexpr int kProducers = 256;
 
 struct FwdArgs {
   const float *x, *mu_w, *rho_w, *mu_b, *rho_b, *pmu_w, *psig_w, *pmu_b, *psig_b;
-  const float* sigma_w;  // optional cached log1p(exp(rho_w)) (bt_params.sigma_w); null: computed in the kernel
+  const float *mu_pk, *sig_pk;  // optional tap-major packed parameters (bt_params.mu_packed / sigma_packed): fast flavour only
   const float *eps_w, *eps_b, *sign_in, *sign_out;
   float* out;
   float* kl_out;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
     wi0 = wo * a.SW - a.PW;
     xoff0 = (b * a.Ci + g * Cig) * a.HW + hi0 * a.W + wi0;
   }
-  const bool quad_rng = (Cig & 3) == 0;  // 4 consecutive channels of one tap are exactly one Philox block
+  const int Cig4 = (Cig + 3) & ~3;  // the draw index pads the channel axis to a multiple of 4: a weight unit is one Philox block
 
   // ---- producer state hoisted out of the stage loop -----------------------------------------------------------------------
   // Weight unit = (row r, channel quad cq, active tap slot ai) -> 4 sampled weights. The (r, cq, ai) of this thread's
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
       u_ai[i] = ai;
       u_kc[i] = (ai << lcc) + 4 * cq;
       u_wb[i] = co * (uint32_t)K + (uint32_t)(4 * cq * T);
-      u_eb[i] = co * (uint32_t)T * (uint32_t)Cig + (uint32_t)(4 * cq);
+      u_eb[i] = co * (uint32_t)T * (uint32_t)Cig4 + (uint32_t)(4 * cq);
       if (u < nunits_full && co_g < a.Cog) u_ok |= 1u << i;
     }
   }
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
       colbase[j] = ml;
     }
   }
-  const float* const sig_or_rho = a.sigma_w ? a.sigma_w : a.rho_w;
-  const bool have_sigma = a.sigma_w != nullptr;
+  const float* const sig_or_rho = a.rho_w;
+  const bool have_sigma = false;  // the general kernel always computes softplus itself
 
   // One stage of producer work. All global loads of the stage (weights, then activations) are issued before any of
   // them is consumed, unconditionally on clamped offsets and with no select between them (a load under a per-lane
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
         const int ci = c0 + ((u_kc[i]) & (CCs - 1));
         const bool uv = ((u_ok >> i) & 1u) && u_ai[i] < na_s;
         const uint32_t base = u_wb[i] + (uint32_t)(c0 * T + tap);           // natural [co][ci][tap] offset of channel ci
-        ue0[i] = u_eb[i] + (uint32_t)(tap * Cig + c0);                        // tap-major draw index of channel ci
+        ue0[i] = u_eb[i] + (uint32_t)(tap * Cig4 + c0);                        // tap-major draw index of channel ci
         unsigned val = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -476,22 +476,9 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
     if (pst) a.dbg[251] = __builtin_amdgcn_s_memtime();
     // -------- draws (independent of every load above) ----------------------------------------------------------------------
     if constexpr (!INJ) {
-      if (quad_rng) {
 #pragma unroll
-        for (int i = 0; i < UMAX; ++i)
-          if (uval[i]) philox_normal4(key_w, sample, ue0[i] >> 2, ep[i]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < UMAX; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (uval[i] & (1u << j)) {
-              float z[4];
-              philox_normal4(key_w, sample, (ue0[i] + j) >> 2, z);
-              const int sel = (int)((ue0[i] + j) & 3);
-              ep[i][j] = sel == 0 ? z[0] : sel == 1 ? z[1] : sel == 2 ? z[2] : z[3];
-            }
-      }
+      for (int i = 0; i < UMAX; ++i)
+        if (uval[i]) philox_normal4(key_w, sample, ue0[i] >> 2, ep[i]);
     }
     if (pst) a.dbg[252] = __builtin_amdgcn_s_memtime();
     // -------- sampled weights -> LDS (transposed) ---------------------------------------------------------------------------

@@ -13,26 +13,24 @@ int set_error(int code, const char* msg) {
   return code;
 }
 
-// out[s][r][c][t] (natural order) <- the tap-major eps stream the fused kernels consume (bt_hip.h).
-// One thread per Philox block: 4 consecutive values of e = (r*taps + t)*inner + c.
+// out[s][r][c][t] (natural order) <- the tap-major, quad-aligned eps stream the fused kernels consume (bt_hip.h).
+// One thread per Philox block: 4 consecutive channels of one (row, tap).
 __global__ __launch_bounds__(256) void rng_normal_fill_kernel(RngKey k, const uint32_t* call_base, uint32_t sample0, long long rows,
                                                               long long inner, long long taps, float* __restrict__ out) {
   if (call_base) k.call += *call_base;
+  const long long inner4 = (inner + 3) & ~3ll;
   const long long n = rows * inner * taps;
-  const long long nq = (n + 3) >> 2;
+  const long long nq = rows * taps * (inner4 >> 2);
   const int s = blockIdx.y;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long long)gridDim.x * 256) {
     float z[4];
     philox_normal4(k, sample0 + s, (uint32_t)q, z);
+    const long long e = q * 4;
+    const long long c0 = e % inner4, rt = e / inner4;
+    const long long t = rt % taps, r = rt / taps;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long long e = q * 4 + j;
-      if (e < n) {
-        const long long c = e % inner, rt = e / inner;
-        const long long t = rt % taps, r = rt / taps;
-        out[(long long)s * n + (r * inner + c) * taps + t] = z[j];
-      }
-    }
+    for (int j = 0; j < 4; ++j)
+      if (c0 + j < inner) out[(long long)s * n + (r * inner + c0 + j) * taps + t] = z[j];
   }
 }
 
@@ -44,8 +42,23 @@ __global__ __launch_bounds__(256) void rng_sign_fill_kernel(RngKey k, const uint
     out[(long long)s * n + i] = hash_sign(key, (uint32_t)i);
 }
 
-__global__ __launch_bounds__(256) void softplus_kernel(const float* __restrict__ rho, float* __restrict__ sigma, long long n) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) sigma[i] = softplus(rho[i]);
+// packed[(co*T + t)*C4 + c] <- natural[co][c][t]; one thread per packed element (reads are strided, done once per
+// parameter update; writes are coalesced).
+__global__ __launch_bounds__(256) void pack_params_kernel(const float* __restrict__ mu, const float* __restrict__ rho, long long Co,
+                                                          long long C, long long T, float* __restrict__ mu_p, float* __restrict__ sg_p) {
+  const long long C4 = (C + 3) & ~3ll, n = Co * T * C4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long c = i % C4, rt = i / C4;
+    const long long t = rt % T, co = rt / T;
+    float m = 0.f, sg = 0.f;
+    if (c < C) {
+      const long long src = (co * C + c) * T + t;
+      m = mu[src];
+      sg = softplus(rho[src]);
+    }
+    mu_p[i] = m;
+    sg_p[i] = sg;
+  }
 }
 
 // One block per batch row b: for each sample softmax over C classes, accumulate probabilities,
@@ -107,9 +120,8 @@ extern "C" int bt_rng_normal_fill(const bt_rng* rng, uint32_t tensor_id, int32_t
   using namespace bt;
   if (!rng || !out || S <= 0 || rows <= 0 || inner <= 0 || taps <= 0 || tensor_id > 3 || S > 65535)
     return set_error(BT_ERR_BAD_ARG, "bt_rng_normal_fill: bad argument");
-  const long long n = (long long)rows * inner * taps;
-  if (n > (1ll << 34)) return set_error(BT_ERR_UNSUPPORTED, "bt_rng_normal_fill: tensor too large");
-  const long long nq = (n + 3) >> 2;
+  const long long nq = (long long)rows * taps * (((long long)inner + 3) >> 2);
+  if (nq > (1ll << 32)) return set_error(BT_ERR_UNSUPPORTED, "bt_rng_normal_fill: tensor too large");
   int gx = (int)((nq + 255) / 256);
   if (gx > 2048) gx = 2048;
   hipLaunchKernelGGL(rng_normal_fill_kernel, dim3(gx, S), dim3(256), 0, (hipStream_t)stream, make_key(*rng, tensor_id), rng->call_base_dev,
@@ -141,11 +153,14 @@ extern "C" int bt_mc_epilogue(int32_t S, int32_t B, int32_t C, const float* logi
   return check_launch("bt_mc_epilogue");
 }
 
-extern "C" int bt_softplus(const float* rho, float* sigma, int64_t n, bt_stream_t stream) {
+extern "C" int bt_pack_params(const float* mu_w, const float* rho_w, int64_t Co, int64_t Ci, int64_t taps, float* mu_packed,
+                              float* sigma_packed, bt_stream_t stream) {
   using namespace bt;
-  if (!rho || !sigma || n <= 0) return set_error(BT_ERR_BAD_ARG, "bt_softplus: bad argument");
+  if (!mu_w || !rho_w || !mu_packed || !sigma_packed || Co <= 0 || Ci <= 0 || taps <= 0) return set_error(BT_ERR_BAD_ARG, "bt_pack_params: bad argument");
+  const long long n = (long long)Co * taps * ((Ci + 3) & ~3ll);
   int gx = (int)((n + 255) / 256);
   if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(softplus_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, rho, sigma, (long long)n);
-  return check_launch("bt_softplus");
+  hipLaunchKernelGGL(pack_params_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, mu_w, rho_w, (long long)Co, (long long)Ci, (long long)taps,
+                     mu_packed, sigma_packed);
+  return check_launch("bt_pack_params");
 }

@@ -14,17 +14,19 @@ def conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, dh, dw):
 def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=None, S=1, shared_x=True,
                   priors=None, eps_w=None, eps_b=None, sign_in=None, sign_out=None,
                   seed=0, call=0, layer_id=0, sample0=0, call_base=None, want_kl=False, workspace_owner="functional",
-                  post_scale=None, post_shift=None, residual=None, relu=False, sigma_w=None):
+                  post_scale=None, post_shift=None, residual=None, relu=False, packed=None):
     """x: [B, In] (conv=None) or [B, Ci, H, W]; when ``shared_x`` is False x holds S stacked batches
     ([S*B, ...]).  conv: dict(stride=(sh,sw), padding=(ph,pw), dilation=(dh,dw), groups=g) for Conv2d.
     priors: (prior_mu_w, prior_sigma_w, prior_mu_b, prior_sigma_b) -- required when want_kl.
     eps_*/sign_*: injected draws with a leading S axis, or None for the on-chip generators.
     post_scale/post_shift [Co], residual ([S*B, ...] like out, or [B, ...] shared), relu: fused output stage
-    (v*scale+shift, +residual, max(.,0)).  Returns (out [S*B, ...], kl or None)."""
+    (v*scale+shift, +residual, max(.,0)).  packed: (mu_packed, sigma_packed) from pack_params() -- selects the fast kernel.
+    Returns (out [S*B, ...], kl or None)."""
     x = _lib.dev_f32(x, "input")
     dev = x.device
     tens = dict(mu_w=mu_w, rho_w=rho_w, mu_b=mu_b, rho_b=rho_b, eps_w=eps_w, eps_b=eps_b, sign_in=sign_in, sign_out=sign_out,
-                post_scale=post_scale, post_shift=post_shift, residual=residual, sigma_w=sigma_w)
+                post_scale=post_scale, post_shift=post_shift, residual=residual, mu_packed=None if packed is None else packed[0],
+                sigma_packed=None if packed is None else packed[1])
     for k, t in tens.items():
         t = _lib.dev_f32(t, k)
         if t is not None and t.device != dev:
@@ -61,7 +63,7 @@ def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=Non
         kl = torch.empty((), dtype=torch.float32, device=dev)
         ws = _lib.workspace(workspace_owner, dev)
     P = _lib.bt_params(tens["mu_w"].data_ptr(), tens["rho_w"].data_ptr(), _lib.ptr(tens["mu_b"]), _lib.ptr(tens["rho_b"]),
-                       _lib.ptr(pr[0]), _lib.ptr(pr[1]), _lib.ptr(pr[2]), _lib.ptr(pr[3]), _lib.ptr(tens["sigma_w"]))
+                       _lib.ptr(pr[0]), _lib.ptr(pr[1]), _lib.ptr(pr[2]), _lib.ptr(pr[3]), _lib.ptr(tens["mu_packed"]), _lib.ptr(tens["sigma_packed"]))
     R = _lib.bt_rng(int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(call_base), int(call) & 0xFFFFFFFF, int(layer_id), int(sample0), 0)
     D = _lib.bt_draws(_lib.ptr(tens["eps_w"]), _lib.ptr(tens["eps_b"]), _lib.ptr(tens["sign_in"]), _lib.ptr(tens["sign_out"]), R)
     E = None
@@ -95,7 +97,7 @@ def rng_fill_normal(seed, call, layer_id, sample0, tensor_id, S, shape, device, 
     """Materialise the on-chip eps stream of a weight ([Co, Ci/g, kh, kw] or [Out, In]) or bias ([Co]) tensor
     -> [S, *shape].  The stream is tap-major (include/bt_hip.h), the returned tensor is in natural order."""
     shape = tuple(shape)
-    rows, inner = shape[0], (shape[1] if len(shape) > 1 else 1)
+    rows, inner = (shape[0], shape[1]) if len(shape) > 1 else (1, shape[0])   # a vector is one row (bias: block co >> 2)
     taps = 1
     for d in shape[2:]:
         taps *= d
@@ -117,12 +119,19 @@ def rng_fill_sign(seed, call, layer_id, sample0, tensor_id, S, shape, device, ca
     return out
 
 
-def softplus(rho):
-    """log1p(exp(rho)) with the kernels' device function (fills the sigma cache of a layer)."""
-    rho = _lib.dev_f32(rho, "rho")
-    out = torch.empty_like(rho)
-    _lib.check(_lib.lib().bt_softplus(rho.data_ptr(), out.data_ptr(), rho.numel(), _lib.stream_ptr()))
-    return out
+def pack_params(mu_w, rho_w):
+    """Tap-major re-layout of a layer's (mu, softplus(rho)) -> (mu_packed, sigma_packed), each [Co, taps, Ci4]
+    (include/bt_hip.h, bt_params). A cache of a pure function of the parameters; rebuild when they change."""
+    mu_w, rho_w = _lib.dev_f32(mu_w, "mu_w"), _lib.dev_f32(rho_w, "rho_w")
+    Co, Ci = mu_w.shape[0], mu_w.shape[1]
+    taps = 1
+    for d in mu_w.shape[2:]:
+        taps *= d
+    C4 = (Ci + 3) // 4 * 4
+    mp = torch.empty((Co, taps, C4), dtype=torch.float32, device=mu_w.device)
+    sp = torch.empty_like(mp)
+    _lib.check(_lib.lib().bt_pack_params(mu_w.data_ptr(), rho_w.data_ptr(), Co, Ci, taps, mp.data_ptr(), sp.data_ptr(), _lib.stream_ptr()))
+    return mp, sp
 
 
 def mc_epilogue(logits):

@@ -54,7 +54,7 @@ class FusedBayesLayer(BaseVariationalLayer_):
         self.post_relu = False    # fused output stage, set by bayesian_torch_amd.fuse (inference-time folding)
         self.register_buffer("post_scale", None, persistent=False)
         self.register_buffer("post_shift", None, persistent=False)
-        self._sigma_cache = None   # (rho version, rho data_ptr, sigma tensor): softplus(rho) is a pure function of rho
+        self._sigma_cache = None   # ((versions, pointers), (mu_packed, sigma_packed)): a pure function of (mu, rho)
         self.inject_draw = None   # test hook: dict(eps_w [S,*w], eps_b, sign_in, sign_out) consumed instead of a fresh draw
         self.init_parameters()
         self.quant_prepare = False
@@ -96,13 +96,14 @@ class FusedBayesLayer(BaseVariationalLayer_):
         return _lib.kl_normal(segs, layer_ids=[0] * len(segs), owner=("layer", self._layer_id))
 
     # ------------------------------------------------------------------ forward
-    def _sigma(self):
-        """softplus(rho) cached until rho changes (in-place update bumps ._version; a new tensor changes data_ptr)."""
-        rho = self._w("rho")
-        key = (rho._version, rho.data_ptr())
+    def _packed(self):
+        """(mu_packed, sigma_packed): tap-major copies of (mu, softplus(rho)) for the fast kernel, rebuilt when a
+        parameter changes (in-place updates bump ._version; a new tensor changes data_ptr)."""
+        mu, rho = self._w("mu"), self._w("rho")
+        key = (mu._version, mu.data_ptr(), rho._version, rho.data_ptr())
         c = self._sigma_cache
         if c is None or c[0] != key:
-            c = (key, F.softplus(rho.detach()))
+            c = (key, F.pack_params(mu.detach(), rho.detach()))
             self._sigma_cache = c
         return c[1]
 
@@ -168,7 +169,7 @@ class FusedBayesLayer(BaseVariationalLayer_):
                                   sign_in=draw.get("sign_in"), sign_out=draw.get("sign_out"), seed=seed, call=call,
                                   layer_id=self._layer_id, sample0=sample0, call_base=call_base, want_kl=want_kl,
                                   workspace_owner=("layer", self._layer_id), post_scale=self.post_scale, post_shift=self.post_shift,
-                                  residual=residual, relu=self.post_relu, sigma_w=self._sigma())
+                                  residual=residual, relu=self.post_relu, packed=self._packed())
         self._last = dict(draw=draw or None, rng=(seed, call_base, call, self._layer_id, sample0), S=S,
                           x_shape=(B,) + tuple(x.shape[1:]), out_shape=(B,) + tuple(out.shape[1:]))
         if lead is not None:

@@ -70,8 +70,12 @@ typedef struct bt_params {
   const float *mu_b, *rho_b; /* [Co] or both NULL */
   const float *prior_mu_w, *prior_sigma_w;
   const float *prior_mu_b, *prior_sigma_b;
-  const float *sigma_w; /* optional: log1p(exp(rho_w)) precomputed by bt_softplus (a cache of a pure function of rho_w;
-                           the kernel skips its own softplus). NULL: the kernel computes it from rho_w. */
+  /* optional tap-major re-layout of the parameters, built by bt_pack_params and valid until mu_w / rho_w change:
+   * mu_packed[(co*T + tap)*Ci4 + ci] = mu_w[co][ci][tap], sigma_packed[...] = log1p(exp(rho_w[co][ci][tap])),
+   * Ci4 = Ci/groups rounded up to a multiple of 4 (padding holds 0). With them a weight unit (4 channels of one tap) is one
+   * 16-byte load at the byte offset of its draw index, pruned taps are never touched in memory, and the kernel does no
+   * softplus. Both NULL: the general kernel reads the natural layout. */
+  const float *mu_packed, *sigma_packed;
 } bt_params;
 
 /* Injected draws (NULL => generate on chip). Layouts: eps_w [S][Co*K],
@@ -152,17 +156,19 @@ int bt_kl_normal(int32_t n_segments, const float *const *mu, const float *const 
                                                     sum_layers( sum_{segments of layer} mean ) like get_kl_loss */,
                  uint32_t flags, float *kl_out /* [1] */, void *workspace, size_t workspace_bytes, bt_stream_t stream);
 
-/* sigma = log1p(exp(rho)) elementwise with the kernels' own device function (bit-identical to what a fused forward
- * computes in place); fills the optional bt_params.sigma_w cache. */
-int bt_softplus(const float *rho, float *sigma, int64_t n, bt_stream_t stream);
+/* Fills bt_params.mu_packed / sigma_packed (each Co * taps * Ci4 floats) from the natural [Co][Ci][taps] tensors; sigma uses
+ * the kernels' own softplus, so a forward with or without the packed copies is bit-identical. */
+int bt_pack_params(const float *mu_w, const float *rho_w, int64_t Co, int64_t Ci, int64_t taps,
+                   float *mu_packed, float *sigma_packed, bt_stream_t stream);
 
 /* The on-chip draws, materialised (test / replay hook: the fused kernels never call these).
  * They emit exactly the streams the fused kernels consume for (rng, tensor_id):
  * tensor_id 0 = eps_w, 1 = eps_b, 2 = sign_in, 3 = sign_out.
  * Stream definition. eps element (row r, inner index c, tap t) of a [rows][inner][taps] tensor (a conv kernel
- * [Co][Ci/g][kh*kw]; Linear and bias: taps = 1) is normal number (e & 3) of Philox block (e >> 2) with
- * e = (r*taps + t)*inner + c  -- tap-major, so the 4 values of one Philox block are 4 consecutive input channels
- * of ONE tap and a kernel that skips taps which only ever meet zero padding skips their RNG as well.
+ * [Co][Ci/g][kh*kw]; Linear and bias: taps = 1) is normal number (c & 3) of Philox block (e >> 2) with
+ * e = (r*taps + t)*inner4 + c,  inner4 = inner rounded up to a multiple of 4  -- tap-major and quad-aligned, so the
+ * 4 values of one Philox block are 4 consecutive input channels of ONE tap: a kernel that skips taps which only ever
+ * meet zero padding skips their RNG as well, and no block straddles two taps.
  * out is [S][rows*inner*taps] in the tensor's natural memory order. Signs: element i of the flat tensor. */
 int bt_rng_normal_fill(const bt_rng *rng, uint32_t tensor_id, int32_t S, int64_t rows, int64_t inner, int64_t taps,
                        float *out, bt_stream_t stream);

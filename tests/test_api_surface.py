@@ -166,7 +166,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from bayesian_torch_amd import _lib
-    assert ctypes.sizeof(_lib.bt_rng) == 32 and ctypes.sizeof(_lib.bt_params) == 64
+    assert ctypes.sizeof(_lib.bt_rng) == 32 and ctypes.sizeof(_lib.bt_params) == 80
     assert ctypes.sizeof(_lib.bt_draws) == 64 and ctypes.sizeof(_lib.bt_conv2d_geom) == 56 and ctypes.sizeof(_lib.bt_epilogue) == 40
 
 

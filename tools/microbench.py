@@ -29,9 +29,9 @@ rho = (torch.randn(Co, Ci, k, k, device=dev) * 0.1 - 3)
 x = torch.randn((a.B if a.shared else a.S * a.B), Ci, H, H, device=dev)
 conv = dict(stride=(st, st), padding=(pd, pd), dilation=(1, 1), groups=1)
 pri = (torch.zeros_like(mu), torch.ones_like(mu), None, None)
-sig = F.softplus(rho) if a.sigma else None
+sig = F.pack_params(mu, rho) if a.sigma else None
 def run(i):
-    return F.fused_forward(x, mu, rho, flip=a.flip, conv=conv, S=a.S, shared_x=a.shared, priors=pri, want_kl=a.kl, seed=1, call=i, layer_id=3, sigma_w=sig)
+    return F.fused_forward(x, mu, rho, flip=a.flip, conv=conv, S=a.S, shared_x=a.shared, priors=pri, want_kl=a.kl, seed=1, call=i, layer_id=3, packed=sig)
 for i in range(3):
     out, _ = run(i)
 torch.cuda.synchronize()

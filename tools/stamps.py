@@ -19,7 +19,7 @@ L = _lib.lib(); L.bt_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]; L.bt_d
 for i in range(3):
     F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=i, layer_id=3)
 L.bt_debug_set_stamp_buffer(buf.data_ptr())
-F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=9, layer_id=3, sigma_w=(F.softplus(rho) if a.sigma else None))
+F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=9, layer_id=3, packed=(F.pack_params(mu, rho) if a.sigma else None))
 torch.cuda.synchronize()
 L.bt_debug_set_stamp_buffer(None)
 t = buf.cpu().tolist()
