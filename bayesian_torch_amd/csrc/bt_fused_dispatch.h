@@ -49,7 +49,7 @@ static int launch_cfg(FwdArgs& a, hipStream_t stream) {
   const long long total = (long long)a.G * a.n_tiles * a.S * a.m_tiles;
   if (total <= 0 || total > 0x7FFFFFFFll) return set_error(BT_ERR_UNSUPPORTED, "fused forward: grid too large");
   a.total_blocks = (int)total;
-  a.kl_slices = total < 4096 ? (int)total : 4096;
+  a.kl_slices = total < 256 ? (int)total : 256;  // workgroups that sweep a slice of the weights for KL (4 wave slots each)
   if constexpr (!INJ) {  // injected draws are the parity/debug mode: always the general kernel
     if (fast_ok<BM, LINEAR>(a)) {
       auto fk = fused_fast_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, false>;

@@ -615,7 +615,6 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
   float* const bias1 = smem + BN;  // flipout: sigma_b*eps_b
   float* const osc = smem + 2 * BN;  // output stage: per-channel scale (1 when absent)
   float* const osh = smem + 3 * BN;  //               per-channel shift (0 when absent)
-  double kl_acc = 0.0;
   const bool kl_block = a.do_kl && (int)blockIdx.x < a.kl_slices;
 
   // The two roles are separate control-flow arms with the same number of workgroup barriers, so the accumulator
@@ -660,13 +659,16 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
     }
     __syncthreads();
   } else {
-    // consumers sweep this workgroup's slice of the weights for KL while the producers fill stage 0
     if (kl_block) {
+      // KL: sweep this workgroup's slice of the weights while the producers fill stage 0, then publish one fp64 partial
+      // PER WAVE right away -- before this workgroup has dirtied L2 with its outputs, so the agent-scope release that the
+      // hand-off needs has almost nothing to write back -- and let the last-arriving wave finish in fixed slot order.
       long long chunk = (a.w_elems + a.kl_slices - 1) / a.kl_slices;
       chunk = (chunk + 3) & ~3ll;
       const long long lo = (long long)blockIdx.x * chunk;
       const long long hi = (lo + chunk < a.w_elems) ? lo + chunk : a.w_elems;
       const bool v4 = ((((uintptr_t)a.mu_w | (uintptr_t)a.rho_w | (uintptr_t)a.pmu_w | (uintptr_t)a.psig_w) & 15u) == 0);
+      double kl_acc = 0.0;
       long long i = lo + 4ll * ptid;
       if (v4) {
         for (; i + 3 < hi; i += 1024) {
@@ -680,6 +682,25 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
       for (; i < hi; i += 1024)  // tail quad / unaligned bases
         for (int j = 0; j < 4; ++j)
           if (i + j < hi) kl_acc += (double)kl_term(a.mu_w[i + j], softplus(a.rho_w[i + j]), a.pmu_w[i + j], a.psig_w[i + j]);
+      const double wsum = wave_sum(kl_acc);
+      const int nslots = 4 * a.kl_slices;
+      int last = 0;
+      if (lane == 0) last = publish_and_ticket(a.slots, a.counter, (int)blockIdx.x * 4 + wave, wsum, (unsigned)nslots) ? 1 : 0;
+      if (__builtin_amdgcn_readfirstlane(last)) {  // this wave arrived last: every slot is published
+        double t = 0.0;
+        for (int q = lane; q < nslots; q += 64) t += __hip_atomic_load(&a.slots[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = wave_sum(t);
+        double bt_ = 0.0;
+        if (a.mu_b)
+          for (int c = lane; c < a.Co; c += 64) bt_ += (double)kl_term(a.mu_b[c], softplus(a.rho_b[c]), a.pmu_b[c], a.psig_b[c]);
+        bt_ = wave_sum(bt_);
+        if (lane == 0) {
+          float kl = (float)(t / (double)a.w_elems);
+          if (a.mu_b) kl += (float)(bt_ / (double)a.Co);
+          a.kl_out[0] = kl;
+          __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // leave the workspace zeroed
+        }
+      }
     }
     __syncthreads();
 
@@ -770,24 +791,6 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
   }
 
   if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[126] = __builtin_amdgcn_s_memtime();
-  // ---- KL finish ------------------------------------------------------------------------------------------------------------
-  if (!kl_block) return;
-  const double bsum = block_sum_all(kl_acc, red);
-  if (tid == 0) misc[1] = publish_and_ticket(a.slots, a.counter, (int)blockIdx.x, bsum, (unsigned)a.kl_slices) ? 1 : 0;
-  __syncthreads();
-  if (!misc[1]) return;
-  double bacc = 0.0;
-  if (a.mu_b)
-    for (int c = tid; c < a.Co; c += kThreads) bacc += (double)kl_term(a.mu_b[c], softplus(a.rho_b[c]), a.pmu_b[c], a.psig_b[c]);
-  const double bias_sum = block_sum_all(bacc, red);
-  if (tid == 0) {
-    double wsum = 0.0;
-    for (int i = 0; i < a.kl_slices; ++i) wsum += __hip_atomic_load(&a.slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float kl = (float)(wsum / (double)a.w_elems);
-    if (a.mu_b) kl += (float)(bias_sum / (double)a.Co);
-    a.kl_out[0] = kl;
-    __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 }  // namespace bt

@@ -179,7 +179,8 @@ def main():
         table, tot_ms, tot_fl = [], 0.0, 0.0
         flip = w["btype"] == "Flipout"
         for n, m in layers:
-            ms = sum(a.elapsed_time(b) for a, b in recs[n]) / len(recs[n])
+            d = sorted(a.elapsed_time(b) for a, b in recs[n])
+            ms = d[len(d) // 2]          # median over the K launches: an event pair also spans host-side hiccups between record and launch
             fl = layer_flops(m, m._last["x_shape"], m._last["out_shape"], flip) * S
             table.append(dict(layer=n, ms=ms, gflop=fl / 1e9, tflops=fl / ms / 1e9, x=list(m._last["x_shape"]), out=list(m._last["out_shape"])))
             tot_ms += ms
@@ -189,7 +190,7 @@ def main():
         roof = dict(bound="mfma", achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     traffic=None, kernel="bt::fused_fwd_kernel (fp32 MFMA implicit GEMM, all tile instances)",
                     launches_per_step=nl, avg_launch_ms=round(tot_ms / nl, 4), flop_per_step=tot_fl,
-                    note="nominal FLOPs (2*B*Co*Ho*Wo*K per sample, padding taps included) x S samples per launch / event-measured launch time")
+                    note="nominal FLOPs (2*B*Co*Ho*Wo*K per sample, padding taps included) x S samples per launch / event-measured launch time (per layer: median over the K steps)")
         if args.layers_json:
             with open(args.layers_json, "w") as f:
                 json.dump(table, f, indent=1)
