@@ -18,7 +18,7 @@ static bool fast_ok(const FwdArgs& a) {
   const int dys = (a.KH - 1) * a.DH, dxs = (a.KW - 1) * a.DW;
   const long long PHt = (long long)(R - 1) * (dys ? a.SH : 1) + dys + 1, PWt = (long long)(Wt - 1) * (dxs ? a.SW : 1) + dxs + 1;
   const long long PCH = NI * PHt * PWt;
-  return 4 * PCH <= (long long)kBK * (BM + 1) && PCH < 65536;
+  return 4 * PCH <= (long long)kBK * ((BM < 256 ? BM : 256) + 1) && PCH < 65536;
 }
 
 template <typename Kern>
@@ -59,11 +59,15 @@ static int launch_cfg(FwdArgs& a, hipStream_t stream) {
       return check_launch("fused forward (fast)");
     }
   }
-  auto kern = fused_fwd_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, INJ>;
-  static bool gflags[64] = {};
-  if (int rc = ensure_lds(kern, lds, gflags)) return rc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(kThreads), lds, stream, a);
-  return check_launch("fused forward");
+  if constexpr (BM <= 256) {
+    auto kern = fused_fwd_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, INJ>;
+    static bool gflags[64] = {};
+    if (int rc = ensure_lds(kern, lds, gflags)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(kThreads), lds, stream, a);
+    return check_launch("fused forward");
+  } else {
+    return set_error(BT_ERR_UNSUPPORTED, "fused forward: this tile exists in the fast flavour only");
+  }
 }
 
 static inline long long tiles_for(const FwdArgs& a, int BN, int BM) {
@@ -83,6 +87,13 @@ static int pick_tile(FwdArgs& a, hipStream_t stream) {
   if (Mdom <= 64) return launch_cfg<64, 64, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);
   if (a.Cog <= 32) return launch_cfg<32, 128, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
   if constexpr (!FLIP) {  // wide tiles: one accumulator set fits in the consumers' registers (Flipout carries two)
+    if constexpr (!LINEAR && !INJ) {  // 512-wide: fast flavour only (x as a patch); halves the weight-synthesis work per MFMA
+      if (Mdom >= 512 && a.Cog <= 64 && tiles_for(a, 64, 512) >= kCUs) {
+        FwdArgs probe = a;
+        probe.patch_ok = 1;
+        if (fast_ok<512, false>(probe)) return launch_cfg<64, 512, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
+      }
+    }
     if (Mdom >= 256 && a.Cog > 64 && tiles_for(a, 128, 256) >= kCUs) return launch_cfg<128, 256, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);
     if (Mdom >= 256 && tiles_for(a, 64, 256) >= kCUs) return launch_cfg<64, 256, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
   }
@@ -93,7 +104,7 @@ static int pick_tile(FwdArgs& a, hipStream_t stream) {
 template <bool FLIP, bool INJ>
 static int launch_flavour(bool linear, FwdArgs& a, hipStream_t stream) {
   if (linear && a.w_vec && a.x_vec) return pick_tile<FLIP, true, true, INJ>(a, stream);   // float4 fast path
-  if (a.HoWo == 1 || a.pixel_major) return pick_tile<FLIP, false, true, INJ>(a, stream);  // incl. any other Linear: a 1x1 conv
+  if (a.HoWo == 1 || a.pixel_major || a.out_vec4) return pick_tile<FLIP, false, true, INJ>(a, stream);  // incl. any other Linear: a 1x1 conv
   return pick_tile<FLIP, false, false, INJ>(a, stream);
 }
 

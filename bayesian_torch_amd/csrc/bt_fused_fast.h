@@ -20,8 +20,9 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
   constexpr int TN = WTN / 32, TM = WTM / 32;
   constexpr int WS = BN + 1, XS = BM + 1;
   constexpr int NW = FLIP ? 2 : 1;
-  constexpr int W_WORDS = kBK * WS, X_WORDS = kBK * XS, BUF_WORDS = NW * (W_WORDS + X_WORDS);
-  static_assert(TN >= 1 && TM >= 1 && WTM * CWM == BM && WTN * CWN == BN && BM <= kProducers, "tile shape");
+  constexpr int W_WORDS = kBK * WS, X_WORDS = kBK * ((BM < 256 ? BM : 256) + 1), BUF_WORDS = NW * (W_WORDS + X_WORDS);
+  static_assert(TN >= 1 && TM >= 1 && WTM * CWM == BM && WTN * CWN == BN, "tile shape");
+  static_assert(!LINEAR || BM <= 256, "a Linear x tile is [k][BM]: only the patch form fits tiles wider than 256");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int4* const taptab = reinterpret_cast<int4*>(smem + 2 * BUF_WORDS);
@@ -234,6 +235,8 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
           rs[i][0] = r4.x, rs[i][1] = r4.y, rs[i][2] = r4.z, rs[i][3] = r4.w;
         }
       }
+      const bool pst = a.dbg && blockIdx.x == 0 && tid == 256 && st == 3;
+      if (pst) a.dbg[251 - 11] = __builtin_amdgcn_s_memtime();
       // ---- loads: activations ----
       constexpr int RP = kProducers / 8;
       constexpr int PC = LINEAR ? 1 : (X_WORDS / CCs + kProducers - 1) / kProducers;
@@ -269,6 +272,7 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
           }
         }
       }
+      if (pst) a.dbg[251] = __builtin_amdgcn_s_memtime();
       // ---- draws (no load feeds them) ----
       if constexpr (!INJ) {
 #pragma unroll
@@ -276,6 +280,7 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
           if ((i == 0 || wave_u0 + kProducers * i < nunits) && c0 < c_lim[i] && u_ai[i] < na_s)
             philox_normal4(key_w, sample, (e_off[i] + tap_e[i] + (uint32_t)c0) >> 2, ep[i]);
       }
+      if (pst) a.dbg[252] = __builtin_amdgcn_s_memtime();
       // ---- sampled weights -> LDS ----
 #pragma unroll
       for (int i = 0; i < UMAX; ++i) {
@@ -289,6 +294,7 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
           }
         }
       }
+      if (pst) a.dbg[253] = __builtin_amdgcn_s_memtime();
       // ---- activations -> LDS ----
       if constexpr (LINEAR) {
         const int kq = ptid & 7, mr = ptid >> 3;
@@ -516,60 +522,98 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
     const float* const sout_s = (FLIP && INJ) ? a.sign_out + (long long)s * a.out_elems : nullptr;
     const float* const res_s = a.ep_res ? a.ep_res + (long long)s * a.ep_res_stride : nullptr;
     const bool relu = a.ep_relu != 0;
+    if (TRANS && a.out_vec4) {
+      // spatial NCHW output through the D[m][co] orientation: a lane owns ONE output channel (bias / scale / shift are lane
+      // constants) and registers 4q..4q+3 are 4 consecutive output positions -> one 16-byte store (and residual load) per 4
+      // values. The host guarantees Ho*Wo % 4 == 0 and 16-byte aligned tensors, so a quad never straddles an image.
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      int b_col = 0, p_col = tile_p;
-      if (!TRANS) {
-        const int ml = m0 + wm * WTM + j * 32 + li;
-        if (pix) {
-          b_col = ml;
-        } else {
-          b_col = ml / a.HoWo;
-          p_col = ml - b_col * a.HoWo;
+      for (int j = 0; j < TM; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ml = m0 + wm * WTM + j * 32 + 8 * q + 4 * lh;
+          const int bq = ml / a.HoWo, pq = ml - bq * a.HoWo;
+          const bool mok = ml < m_lim;
+#pragma unroll
+          for (int i = 0; i < TN; ++i) {
+            const int co_l = wn * WTN + i * 32 + li;
+            const bool ok = mok && n0 + co_l < a.Cog;
+            const uint32_t oidx = ok ? (uint32_t)((bq * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + pq) : 0u;
+            const float b0 = bias0[co_l], sc = osc[co_l], sh = osh[co_l];
+            float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (res_s) r4 = *reinterpret_cast<const float4*>(res_s + oidx);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = __fadd_rn(acc[0][i][j][4 * q + e], b0);
+              if constexpr (FLIP) {
+                const float so = INJ ? sout_s[oidx + e] : hash_sign(skey_out, oidx + e);
+                v[e] = __fadd_rn(v[e], __fmul_rn(__fadd_rn(acc[NW - 1][i][j][4 * q + e], bias1[co_l]), so));
+              }
+              v[e] = __fadd_rn(__fmul_rn(v[e], sc), sh);
+            }
+            v[0] = __fadd_rn(v[0], r4.x), v[1] = __fadd_rn(v[1], r4.y), v[2] = __fadd_rn(v[2], r4.z), v[3] = __fadd_rn(v[3], r4.w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (relu && v[e] < 0.f) ? 0.f : v[e];
+            if (ok) *reinterpret_cast<float4*>(out_s + oidx) = make_float4(v[0], v[1], v[2], v[3]);
+          }
         }
       }
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        uint32_t oi[16];
-        bool okv[16];
-        int col[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          int co_l, ml;
-          if (TRANS) {
-            co_l = wn * WTN + i * 32 + li;
-            ml = m0 + wm * WTM + j * 32 + row;
-            oi[r] = (uint32_t)((ml * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + tile_p);
+    } else {
+  #pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        int b_col = 0, p_col = tile_p;
+        if (!TRANS) {
+          const int ml = m0 + wm * WTM + j * 32 + li;
+          if (pix) {
+            b_col = ml;
           } else {
-            co_l = wn * WTN + i * 32 + row;
-            ml = m0 + wm * WTM + j * 32 + li;
-            oi[r] = (uint32_t)((b_col * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + p_col);
+            b_col = ml / a.HoWo;
+            p_col = ml - b_col * a.HoWo;
           }
-          okv[r] = n0 + co_l < a.Cog && ml < m_lim;
-          col[r] = co_l;
-          if (!okv[r]) oi[r] = 0u;
         }
-        float rsd[16], so[FLIP ? 16 : 1];
-        if (res_s) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) rsd[r] = res_s[oi[r]];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) rsd[r] = 0.f;
-        }
-        if constexpr (FLIP) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) so[r] = INJ ? sout_s[oi[r]] : hash_sign(skey_out, oi[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = __fadd_rn(acc[0][i][j][r], bias0[col[r]]);
-          if constexpr (FLIP) v = __fadd_rn(v, __fmul_rn(__fadd_rn(acc[NW - 1][i][j][r], bias1[col[r]]), so[r]));
-          v = __fadd_rn(__fmul_rn(v, osc[col[r]]), osh[col[r]]);
-          v = __fadd_rn(v, rsd[r]);
-          v = (relu && v < 0.f) ? 0.f : v;
-          if (okv[r]) out_s[oi[r]] = v;
+  #pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          uint32_t oi[16];
+          bool okv[16];
+          int col[16];
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            int co_l, ml;
+            if (TRANS) {
+              co_l = wn * WTN + i * 32 + li;
+              ml = m0 + wm * WTM + j * 32 + row;
+              oi[r] = (uint32_t)((ml * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + tile_p);
+            } else {
+              co_l = wn * WTN + i * 32 + row;
+              ml = m0 + wm * WTM + j * 32 + li;
+              oi[r] = (uint32_t)((b_col * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + p_col);
+            }
+            okv[r] = n0 + co_l < a.Cog && ml < m_lim;
+            col[r] = co_l;
+            if (!okv[r]) oi[r] = 0u;
+          }
+          float rsd[16], so[FLIP ? 16 : 1];
+          if (res_s) {
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) rsd[r] = res_s[oi[r]];
+          } else {
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) rsd[r] = 0.f;
+          }
+          if constexpr (FLIP) {
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) so[r] = INJ ? sout_s[oi[r]] : hash_sign(skey_out, oi[r]);
+          }
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = __fadd_rn(acc[0][i][j][r], bias0[col[r]]);
+            if constexpr (FLIP) v = __fadd_rn(v, __fmul_rn(__fadd_rn(acc[NW - 1][i][j][r], bias1[col[r]]), so[r]));
+            v = __fadd_rn(__fmul_rn(v, osc[col[r]]), osh[col[r]]);
+            v = __fadd_rn(v, rsd[r]);
+            v = (relu && v < 0.f) ? 0.f : v;
+            if (okv[r]) out_s[oi[r]] = v;
+          }
         }
       }
     }

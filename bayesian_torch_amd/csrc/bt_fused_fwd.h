@@ -58,6 +58,7 @@ struct FwdArgs {
   const float *ep_scale, *ep_shift, *ep_res;  // fused output stage (bt_epilogue)
   long long ep_res_stride;
   int ep_relu;
+  int out_vec4;  // spatial output stored as float4 along the pixel index (TRANS orientation; Ho*Wo % 4 == 0, aligned tensors)
   unsigned long long* dbg;  // diagnostic stamps (bt_debug_set_stamp_buffer); null in normal operation
 };
 
@@ -71,7 +72,8 @@ __device__ __forceinline__ int xcd_remap(int orig, int n) {
 
 template <int BN, int BM, bool FLIP>
 constexpr int fused_lds_bytes() {
-  return (2 * (FLIP ? 2 : 1) * (kBK * (BN + 1) + kBK * (BM + 1)) + kMaxTaps * 4 + 24 + 8 + 80) * 4;
+  // the x tile never needs more than 256 columns' worth: wider tiles (fast flavour only) stage x as a patch
+  return (2 * (FLIP ? 2 : 1) * (kBK * (BN + 1) + kBK * ((BM < 256 ? BM : 256) + 1)) + kMaxTaps * 4 + 24 + 8 + 80) * 4;
 }
 
 __device__ __forceinline__ double block_sum_all(double v, double* scratch) {  // 12 waves; result in thread 0
@@ -728,63 +730,101 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
     float* const out_s = a.out + (long long)s * a.out_elems;
     const float* const sout_s = (FLIP && INJ) ? a.sign_out + (long long)s * a.out_elems : nullptr;
     const float* const res_s = a.ep_res ? a.ep_res + (long long)s * a.ep_res_stride : nullptr;
+    const bool relu = a.ep_relu != 0;
+    if (TRANS && a.out_vec4) {
+      // spatial NCHW output through the D[m][co] orientation: a lane owns ONE output channel (bias / scale / shift are lane
+      // constants) and registers 4q..4q+3 are 4 consecutive output positions -> one 16-byte store (and residual load) per 4
+      // values. The host guarantees Ho*Wo % 4 == 0 and 16-byte aligned tensors, so a quad never straddles an image.
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      int b_col = 0, p_col = tile_p;
-      if (!TRANS) {  // lanes run along m: decode this lane's column once
-        const int ml = m0 + wm * WTM + j * 32 + li;
-        if (pix) {
-          b_col = ml;
-        } else {
-          b_col = ml / a.HoWo;
-          p_col = ml - b_col * a.HoWo;
+      for (int j = 0; j < TM; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ml = m0 + wm * WTM + j * 32 + 8 * q + 4 * lh;
+          const int bq = ml / a.HoWo, pq = ml - bq * a.HoWo;
+          const bool mok = ml < m_lim;
+#pragma unroll
+          for (int i = 0; i < TN; ++i) {
+            const int co_l = wn * WTN + i * 32 + li;
+            const bool ok = mok && n0 + co_l < a.Cog;
+            const uint32_t oidx = ok ? (uint32_t)((bq * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + pq) : 0u;
+            const float b0 = bias0[co_l], sc = osc[co_l], sh = osh[co_l];
+            float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (res_s) r4 = *reinterpret_cast<const float4*>(res_s + oidx);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = __fadd_rn(acc[0][i][j][4 * q + e], b0);
+              if constexpr (FLIP) {
+                const float so = INJ ? sout_s[oidx + e] : hash_sign(skey_out, oidx + e);
+                v[e] = __fadd_rn(v[e], __fmul_rn(__fadd_rn(acc[NW - 1][i][j][4 * q + e], bias1[co_l]), so));
+              }
+              v[e] = __fadd_rn(__fmul_rn(v[e], sc), sh);
+            }
+            v[0] = __fadd_rn(v[0], r4.x), v[1] = __fadd_rn(v[1], r4.y), v[2] = __fadd_rn(v[2], r4.z), v[3] = __fadd_rn(v[3], r4.w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (relu && v[e] < 0.f) ? 0.f : v[e];
+            if (ok) *reinterpret_cast<float4*>(out_s + oidx) = make_float4(v[0], v[1], v[2], v[3]);
+          }
         }
       }
-      const bool relu = a.ep_relu != 0;
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        // All reads of the tile (residual, injected signs) are issued before the first dependent instruction:
-        // unconditional loads on clamped indices, selected afterwards (same reason as in produce()).
-        uint32_t oi[16];
-        bool okv[16];
-        int col[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          int co_l, ml;
-          if (TRANS) {  // D[m][co]: lanes along co (HoWo == 1, or pixel-major tiles)
-            co_l = wn * WTN + i * 32 + li;
-            ml = m0 + wm * WTM + j * 32 + row;
-            oi[r] = (uint32_t)((ml * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + tile_p);
-          } else {      // D[co][m]: lanes along the spatial index (NCHW-contiguous)
-            co_l = wn * WTN + i * 32 + row;
-            ml = m0 + wm * WTM + j * 32 + li;
-            oi[r] = (uint32_t)((b_col * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + p_col);
+    } else {
+  #pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        int b_col = 0, p_col = tile_p;
+        if (!TRANS) {  // lanes run along m: decode this lane's column once
+          const int ml = m0 + wm * WTM + j * 32 + li;
+          if (pix) {
+            b_col = ml;
+          } else {
+            b_col = ml / a.HoWo;
+            p_col = ml - b_col * a.HoWo;
           }
-          okv[r] = n0 + co_l < a.Cog && ml < m_lim;
-          col[r] = co_l;
-          if (!okv[r]) oi[r] = 0u;
         }
-        float rs[16], so[FLIP ? 16 : 1];
-        if (res_s) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) rs[r] = res_s[oi[r]];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) rs[r] = 0.f;
-        }
-        if constexpr (FLIP) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) so[r] = INJ ? sout_s[oi[r]] : hash_sign(skey_out, oi[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = __fadd_rn(acc[0][i][j][r], bias0[col[r]]);
-          if constexpr (FLIP) v = __fadd_rn(v, __fmul_rn(__fadd_rn(acc[NW - 1][i][j][r], bias1[col[r]]), so[r]));
-          v = __fadd_rn(__fmul_rn(v, osc[col[r]]), osh[col[r]]);
-          v = __fadd_rn(v, rs[r]);
-          v = (relu && v < 0.f) ? 0.f : v;  // a select, so NaN propagates like torch's relu
-          if (okv[r]) out_s[oi[r]] = v;
+  #pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          // All reads of the tile (residual, injected signs) are issued before the first dependent instruction:
+          // unconditional loads on clamped indices, selected afterwards (same reason as in produce()).
+          uint32_t oi[16];
+          bool okv[16];
+          int col[16];
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            int co_l, ml;
+            if (TRANS) {  // D[m][co]: lanes along co (HoWo == 1, or pixel-major tiles)
+              co_l = wn * WTN + i * 32 + li;
+              ml = m0 + wm * WTM + j * 32 + row;
+              oi[r] = (uint32_t)((ml * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + tile_p);
+            } else {      // D[co][m]: lanes along the spatial index (NCHW-contiguous)
+              co_l = wn * WTN + i * 32 + row;
+              ml = m0 + wm * WTM + j * 32 + li;
+              oi[r] = (uint32_t)((b_col * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + p_col);
+            }
+            okv[r] = n0 + co_l < a.Cog && ml < m_lim;
+            col[r] = co_l;
+            if (!okv[r]) oi[r] = 0u;
+          }
+          float rs[16], so[FLIP ? 16 : 1];
+          if (res_s) {
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) rs[r] = res_s[oi[r]];
+          } else {
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) rs[r] = 0.f;
+          }
+          if constexpr (FLIP) {
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) so[r] = INJ ? sout_s[oi[r]] : hash_sign(skey_out, oi[r]);
+          }
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = __fadd_rn(acc[0][i][j][r], bias0[col[r]]);
+            if constexpr (FLIP) v = __fadd_rn(v, __fmul_rn(__fadd_rn(acc[NW - 1][i][j][r], bias1[col[r]]), so[r]));
+            v = __fadd_rn(__fmul_rn(v, osc[col[r]]), osh[col[r]]);
+            v = __fadd_rn(v, rs[r]);
+            v = (relu && v < 0.f) ? 0.f : v;  // a select, so NaN propagates like torch's relu
+            if (okv[r]) out_s[oi[r]] = v;
+          }
         }
       }
     }

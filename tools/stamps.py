@@ -24,7 +24,7 @@ torch.cuda.synchronize()
 L.bt_debug_set_stamp_buffer(None)
 t = buf.cpu().tolist()
 t0 = t[0]
-print("  detail: setup", t[239]-t[250], " W loads", t[240]-t[239], " rowtab", t[241]-t[240], " X loads", t[251]-t[241])
+print("  fast: start->Wloads-issued", t[240]-t[128+6], " Xloads-issued", t[251]-t[240])
 print("producer phases st3: loads-issued", t[251]-t[250], " draws", t[252]-t[251], " W->LDS", t[253]-t[252], " X->LDS(end)", t[128+7]-t[253])
 print("s_memtime ticks (100 MHz realtime? or shader clock) relative to consumer loop start")
 print("consumer: loop", t[1] - t0, "end-of-kernel", t[126] - t0)
