@@ -187,8 +187,12 @@ def main():
             tot_fl += fl
         nl = len(layers)
         ach = tot_fl / tot_ms / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")   # measured offline: PMC passes cannot run inside this process
+        if args.workload == "cfg3" and S == 32 and fused and os.path.exists(tfile):
+            traffic = json.load(open(tfile))["traffic_bytes_per_launch"]
         roof = dict(bound="mfma", achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                    traffic=None, kernel="bt::fused_fwd_kernel (fp32 MFMA implicit GEMM, all tile instances)",
+                    traffic=traffic, kernel="bt::fused_fwd_kernel (fp32 MFMA implicit GEMM, all tile instances)",
                     launches_per_step=nl, avg_launch_ms=round(tot_ms / nl, 4), flop_per_step=tot_fl,
                     note="nominal FLOPs (2*B*Co*Ho*Wo*K per sample, padding taps included) x S samples per launch / event-measured launch time (per layer: median over the K steps)")
         if args.layers_json:
