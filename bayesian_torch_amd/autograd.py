@@ -1,0 +1,141 @@
+"""Autograd bridge for the fused forward (SURVEY.md section 8(f), rank 1 -- first step).
+
+The forward stays the fused HIP kernel.  Nothing weight-sized is saved for backward: the draws are a pure function of
+the RNG coordinates, so backward REGENERATES eps (and the Flipout signs) with bt_rng_*_fill from the coordinates the
+forward used, rebuilds W_s = mu + softplus(rho) * eps_s, and obtains the three gradients of the contraction
+(d/dx, d/dW, d/db) from ATen's convolution / matmul backward on the GPU; the chain rule to (mu, rho) is applied here:
+
+    dL/dmu  = sum_s dL/dW_s                       dL/drho  = sum_s dL/dW_s * eps_s * sigmoid(rho)
+    (Flipout: mean path feeds mu, perturbation path feeds rho through Delta = softplus(rho) * eps)
+
+This is an interim backward: correct (tests/test_gpu_autograd.py checks it against torch autograd of the oracle on the
+same draws) but not yet fused -- a hand-written HIP dgrad/wgrad with in-kernel regeneration is the next step.
+Reference arithmetic differentiated: layers/variational_layers/linear_variational.py:163-181,
+conv_variational.py:366-385, flipout_layers/linear_flipout.py:149-174, conv_flipout.py:376-417 and the normal-prior
+KL of base_variational_layer.py:68-72.
+"""
+import torch
+import torch.nn.functional as TF
+
+from . import _lib
+from . import functional as F
+
+
+def _contract(x, w, conv):
+    if conv is None:
+        return TF.linear(x, w)
+    return TF.conv2d(x, w, None, conv["stride"], conv["padding"], conv["dilation"], conv["groups"])
+
+
+def _grads(x, w, g, conv, need_x=True):
+    """-> (dL/dx or None, dL/dw) of y = contract(x, w) for upstream g."""
+    if conv is None:
+        return (g @ w if need_x else None), g.t() @ x
+    gx = torch.nn.grad.conv2d_input(x.shape, w, g, conv["stride"], conv["padding"], conv["dilation"], conv["groups"]) if need_x else None
+    gw = torch.nn.grad.conv2d_weight(x, w.shape, g, conv["stride"], conv["padding"], conv["dilation"], conv["groups"])
+    return gx, gw
+
+
+class FusedForward(torch.autograd.Function):
+    """out[S*B, ...] = fused stochastic forward; differentiable in x, mu_w, rho_w, mu_b, rho_b."""
+
+    @staticmethod
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, opts):
+        o = dict(opts)
+        out, _ = F.fused_forward(x, mu_w, rho_w, mu_b, rho_b, flip=o["flip"], conv=o["conv"], S=o["S"], shared_x=o["shared"],
+                                 seed=o["seed"], call=o["call"], layer_id=o["layer_id"], sample0=o["sample0"],
+                                 eps_w=o.get("eps_w"), eps_b=o.get("eps_b"), sign_in=o.get("sign_in"), sign_out=o.get("sign_out"),
+                                 packed=o.get("packed"), workspace_owner=("layer", o["layer_id"]))
+        ctx.o = o
+        ctx.save_for_backward(x, mu_w, rho_w, mu_b, rho_b)
+        ctx.out_shape = tuple(out.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mu_w, rho_w, mu_b, rho_b = ctx.saved_tensors
+        o = ctx.o
+        S, shared, conv, flip = o["S"], o["shared"], o["conv"], o["flip"]
+        dev = x.device
+        g = g.contiguous()
+        B = x.shape[0] // (1 if shared else S)
+        coords = (o["seed"], o["call"], o["layer_id"], o["sample0"])
+        # the draws of the forward, regenerated (or the injected ones)
+        eps_w = o.get("eps_w")
+        if eps_w is None:
+            eps_w = F.rng_fill_normal(*coords, 0, S, mu_w.shape, dev)
+        eps_w = eps_w.reshape((S,) + tuple(mu_w.shape))
+        has_b = mu_b is not None
+        eps_b = o.get("eps_b")
+        if has_b and eps_b is None:
+            eps_b = F.rng_fill_normal(*coords, 1, S, (mu_w.shape[0],), dev)
+        x_s_shape = (B,) + tuple(x.shape[1:])
+        o_s_shape = (B,) + tuple(ctx.out_shape[1:])
+        s_in = s_out = None
+        if flip:
+            s_in, s_out = o.get("sign_in"), o.get("sign_out")
+            if s_in is None:
+                s_in = F.rng_fill_sign(*coords, 2, S, x_s_shape, dev)
+                s_out = F.rng_fill_sign(*coords, 3, S, o_s_shape, dev)
+            s_in, s_out = s_in.reshape((S,) + x_s_shape), s_out.reshape((S,) + o_s_shape)
+        sigma = TF.softplus(rho_w)
+        dsig = torch.sigmoid(rho_w)
+        need_x = ctx.needs_input_grad[0]
+        gx = torch.zeros_like(x) if need_x else None
+        gmu = torch.zeros_like(mu_w)
+        grho = torch.zeros_like(rho_w)
+        gmu_b = torch.zeros_like(mu_b) if has_b else None
+        grho_b = torch.zeros_like(rho_b) if has_b else None
+        red = [0] + list(range(2, g.dim()))          # every axis but the channel axis
+        for s in range(S):
+            xs = x if shared else x[s * B:(s + 1) * B]
+            gs = g[s * B:(s + 1) * B]
+            if not flip:
+                w = mu_w + sigma * eps_w[s]
+                gxs, gw = _grads(xs, w, gs, conv, need_x)
+                gmu += gw
+                grho += gw * eps_w[s] * dsig
+                if has_b:
+                    gb = gs.sum(red)
+                    gmu_b += gb
+                    grho_b += gb * eps_b[s] * torch.sigmoid(rho_b)
+            else:
+                gp = gs * s_out[s]
+                delta = sigma * eps_w[s]
+                gx1, gw_mu = _grads(xs, mu_w, gs, conv, need_x)
+                gx2, gw_d = _grads(xs * s_in[s], delta, gp, conv, need_x)
+                gmu += gw_mu
+                grho += gw_d * eps_w[s] * dsig
+                gxs = (gx1 + gx2 * s_in[s]) if need_x else None
+                if has_b:
+                    gmu_b += gs.sum(red)
+                    grho_b += gp.sum(red) * eps_b[s] * torch.sigmoid(rho_b)
+            if need_x:
+                if shared:
+                    gx += gxs
+                else:
+                    gx[s * B:(s + 1) * B] = gxs
+        return gx, gmu, grho, gmu_b, grho_b, None
+
+
+class KLNormal(torch.autograd.Function):
+    """kl = sum over the given (mu, rho, prior_mu, prior_sigma) groups of mean_i(...), on the HIP KL kernel; grads to mu, rho."""
+
+    @staticmethod
+    def forward(ctx, owner, *tensors):
+        segs = [tuple(tensors[i:i + 4]) for i in range(0, len(tensors), 4)]
+        ctx.save_for_backward(*tensors)
+        return _lib.kl_normal([tuple(t.detach() for t in sg) for sg in segs], layer_ids=[0] * len(segs), owner=owner)
+
+    @staticmethod
+    def backward(ctx, g):
+        t = ctx.saved_tensors
+        grads = [None]
+        for i in range(0, len(t), 4):
+            mu, rho, pm, ps = t[i:i + 4]
+            n = mu.numel()
+            sq = TF.softplus(rho)
+            gmu = (mu - pm) / (ps * ps) * (g / n)
+            grho = (sq / (ps * ps) - 1.0 / sq) * torch.sigmoid(rho) * (g / n)
+            grads += [gmu, grho, None, None]
+        return tuple(grads)

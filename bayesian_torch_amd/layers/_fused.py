@@ -6,7 +6,8 @@ Reference behaviour reproduced (paths under /root/reference/bayesian_torch/layer
   forward(input, return_kl=True)  linear_variational.py:160-204, conv_variational.py:362-407,
                                   flipout_layers/linear_flipout.py:145-197, conv_flipout.py:370-439
   kl_loss()                       linear_variational.py:146-158
-Forward is inference-only in this round (no autograd through the fused kernel yet).
+Training: the same fused forward; gradients come from the autograd bridge (autograd.py: draws regenerated from the RNG
+coordinates, ATen conv/matmul backward) -- a fused HIP backward is the next step.
 """
 import ctypes as C
 import warnings
@@ -93,6 +94,9 @@ class FusedBayesLayer(BaseVariationalLayer_):
     def kl_loss(self):
         check_prior_type(getattr(self, "prior_type", "normal"))
         segs = self._kl_segments()
+        if torch.is_grad_enabled() and any(t.requires_grad for sg in segs for t in sg):
+            from ..autograd import KLNormal
+            return KLNormal.apply(("layer", self._layer_id), *[t for sg in segs for t in sg])
         return _lib.kl_normal(segs, layer_ids=[0] * len(segs), owner=("layer", self._layer_id))
 
     # ------------------------------------------------------------------ forward
@@ -123,9 +127,6 @@ class FusedBayesLayer(BaseVariationalLayer_):
         if want_kl:
             check_prior_type(getattr(self, "prior_type", "normal"))
         x = _lib.dev_f32(x, "input")
-        if torch.is_grad_enabled() and self._w("mu").requires_grad and not _warned[0]:
-            _warned[0] = True
-            warnings.warn("bayesian_torch_amd: the fused forward is inference-only in this build; outputs carry no autograd graph")
         lead = None
         if self._kind == "linear":
             if x.shape[-1] != self.in_features:
@@ -163,13 +164,31 @@ class FusedBayesLayer(BaseVariationalLayer_):
                 raise RuntimeError(f"inject_draw holds {draw['eps_w'].shape[0]} samples, this call computes {S}")
         else:
             draw = self._draw_torch(x, S, B, conv) if rng.get_mode() == "torch" else {}
-        priors = (self.prior_weight_mu, self.prior_weight_sigma, self.prior_bias_mu, self.prior_bias_sigma) if want_kl else None
-        out, kl = F.fused_forward(x, self._w("mu"), self._w("rho"), self.mu_bias, self.rho_bias, flip=self._flip, conv=conv,
-                                  S=S, shared_x=shared, priors=priors, eps_w=draw.get("eps_w"), eps_b=draw.get("eps_b"),
-                                  sign_in=draw.get("sign_in"), sign_out=draw.get("sign_out"), seed=seed, call=call,
-                                  layer_id=self._layer_id, sample0=sample0, call_base=call_base, want_kl=want_kl,
-                                  workspace_owner=("layer", self._layer_id), post_scale=self.post_scale, post_shift=self.post_shift,
-                                  residual=residual, relu=self.post_relu, packed=self._packed())
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or self._w("mu").requires_grad or self._w("rho").requires_grad
+                                                  or (self.mu_bias is not None and self.mu_bias.requires_grad))
+        if needs_grad:
+            # training path: same fused forward kernel, gradients through the autograd bridge (autograd.py)
+            if self.post_scale is not None or residual is not None or self.post_relu:
+                raise RuntimeError("the folded output stage (fuse.py) is inference-only: unfold or run under torch.no_grad()")
+            from ..autograd import FusedForward, KLNormal
+            opts = dict(flip=self._flip, conv=conv, S=S, shared=shared, seed=seed, call=call, layer_id=self._layer_id, sample0=sample0,
+                        eps_w=draw.get("eps_w"), eps_b=draw.get("eps_b"), sign_in=draw.get("sign_in"), sign_out=draw.get("sign_out"),
+                        packed=self._packed())
+            if call_base is not None:
+                raise RuntimeError("graph-replayed draws (call_base) are not supported on the training path")
+            out = FusedForward.apply(x, self._w("mu"), self._w("rho"), self.mu_bias, self.rho_bias, opts)
+            kl = None
+            if want_kl:
+                flat = [t for sg in self._kl_segments() for t in sg]
+                kl = KLNormal.apply(("layer", self._layer_id), *flat)
+        else:
+            priors = (self.prior_weight_mu, self.prior_weight_sigma, self.prior_bias_mu, self.prior_bias_sigma) if want_kl else None
+            out, kl = F.fused_forward(x, self._w("mu"), self._w("rho"), self.mu_bias, self.rho_bias, flip=self._flip, conv=conv,
+                                      S=S, shared_x=shared, priors=priors, eps_w=draw.get("eps_w"), eps_b=draw.get("eps_b"),
+                                      sign_in=draw.get("sign_in"), sign_out=draw.get("sign_out"), seed=seed, call=call,
+                                      layer_id=self._layer_id, sample0=sample0, call_base=call_base, want_kl=want_kl,
+                                      workspace_owner=("layer", self._layer_id), post_scale=self.post_scale, post_shift=self.post_shift,
+                                      residual=residual, relu=self.post_relu, packed=self._packed())
         self._last = dict(draw=draw or None, rng=(seed, call_base, call, self._layer_id, sample0), S=S,
                           x_shape=(B,) + tuple(x.shape[1:]), out_shape=(B,) + tuple(out.shape[1:]))
         if lead is not None:

@@ -81,7 +81,15 @@ def get_kl_loss(m):
             n += 1
         elif hasattr(layer, "kl_loss"):
             others.append(layer)
-    kl = _lib.kl_normal(segs, layer_ids=lids, owner=("model", id(m))) if segs else None
+    kl = None
+    if segs:
+        import torch
+        if torch.is_grad_enabled() and any(t.requires_grad for sg in segs for t in sg):   # training: per-layer differentiable KL
+            for layer in m.modules():
+                if isinstance(layer, FusedBayesLayer):
+                    kl = layer.kl_loss() if kl is None else kl + layer.kl_loss()
+        else:
+            kl = _lib.kl_normal(segs, layer_ids=lids, owner=("model", id(m)))
     for layer in others:     # foreign modules with a kl_loss of their own
         kl = layer.kl_loss() if kl is None else kl + layer.kl_loss()
     return kl
