@@ -109,12 +109,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("BT_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 path with ranks sharing one GPU
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     elif args.gpus > 1:
         print("bench.py: --gpus > 1 must be launched through torch.distributed.run", file=sys.stderr)
         sys.exit(2)
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))
     w = WORKLOADS[args.workload]
     S = args.samples or w["S"]
     net = build_model(w, dev)
@@ -157,7 +162,7 @@ def main():
 
     # ---- roofline pass: same steps, an event pair around every fused-forward launch --------------------------
     roof = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline:   # every rank runs the same steps (they contain the collective); only rank 0 keeps the numbers
         layers = H.bayes_layers(net)
         recs = {n: [] for n, _ in layers}
         handles = []
@@ -177,6 +182,7 @@ def main():
         for h in handles:
             h.remove()
         table, tot_ms, tot_fl = [], 0.0, 0.0
+        barrier()
         flip = w["btype"] == "Flipout"
         for n, m in layers:
             d = sorted(a.elapsed_time(b) for a, b in recs[n])
@@ -189,16 +195,16 @@ def main():
         ach = tot_fl / tot_ms / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")   # measured offline: PMC passes cannot run inside this process
-        if args.workload == "cfg3" and S == 32 and fused and os.path.exists(tfile):
+        if args.workload == "cfg3" and S == 32 and fused and world == 1 and os.path.exists(tfile):
             traffic = json.load(open(tfile))["traffic_bytes_per_launch"]
         roof = dict(bound="mfma", achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                    traffic=traffic, kernel="bt::fused_fwd_kernel (fp32 MFMA implicit GEMM, all tile instances)",
+                    traffic=traffic, kernel="bt::fused_fast_kernel / bt::fused_fwd_kernel (fp32 MFMA implicit GEMM, all tile instances)",
                     launches_per_step=nl, avg_launch_ms=round(tot_ms / nl, 4), flop_per_step=tot_fl,
                     note="nominal FLOPs (2*B*Co*Ho*Wo*K per sample, padding taps included) x S samples per launch / event-measured launch time (per layer: median over the K steps)")
-        if args.layers_json:
+        if args.layers_json and rank == 0:
             with open(args.layers_json, "w") as f:
                 json.dump(table, f, indent=1)
-        for r in table:
+        for r in (table if rank == 0 else []):
             print(f"  {r['layer']:24s} {r['ms']*1e3:9.1f} us  {r['gflop']:8.2f} GF  {r['tflops']:7.2f} TF/s", file=sys.stderr)
 
     cpu = None
@@ -216,6 +222,7 @@ def main():
                     roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
