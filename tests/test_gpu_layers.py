@@ -168,3 +168,45 @@ def test_mc_epilogue_matches_oracle():
         assert_close(packed[:B * Cc].reshape(B, Cc), p, 1e-5, 1e-6, "psum")
         assert_close(packed[B * Cc:B * Cc + B], e, 1e-5, 1e-6, "entropy")
         assert_close(packed[B * Cc + B:].reshape(B, Cc), l, 1e-5, 1e-6, "lsum")
+
+
+def test_fast_kernel_is_bit_identical_to_general_kernel(tmp_path):
+    """The specialised kernel (packed parameters, LDS patch; what bench.py runs) and the general kernel (what the golden
+    fixtures with injected draws run) use the same arithmetic order: on the same on-chip draws their outputs are equal bit
+    for bit. BT_FORCE_GENERIC is read once per process, hence two child processes."""
+    import os
+    import subprocess
+    import sys
+    script = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from bayesian_torch_amd import functional as F
+torch.manual_seed(0)
+dev = torch.device("cuda")
+outs = []
+for (Ci, Co, k, st, pd, H, B, S, flip) in [(64, 64, 3, 1, 1, 8, 8, 2, False), (128, 256, 3, 2, 1, 4, 16, 2, False), (256, 256, 3, 1, 1, 2, 32, 2, True),
+                                            (512, 512, 3, 1, 1, 1, 64, 2, False), (3, 64, 7, 2, 3, 32, 4, 2, False), (64, 128, 1, 2, 0, 8, 8, 1, True)]:
+    mu = torch.randn(Co, Ci, k, k, device=dev) * 0.1
+    rho = torch.randn(Co, Ci, k, k, device=dev) * 0.1 - 3
+    x = torch.randn(S * B, Ci, H, H, device=dev)
+    conv = dict(stride=(st, st), padding=(pd, pd), dilation=(1, 1), groups=1)
+    pri = (torch.zeros_like(mu), torch.ones_like(mu), None, None)
+    o, kl = F.fused_forward(x, mu, rho, flip=flip, conv=conv, S=S, shared_x=False, priors=pri, want_kl=True, seed=5, call=1, layer_id=2,
+                            packed=F.pack_params(mu, rho))
+    outs += [o.flatten().cpu(), kl.reshape(1).cpu()]
+for (In, Out, B, S, flip) in [(512, 10, 128, 2, False), (3072, 512, 64, 1, True)]:
+    mu = torch.randn(Out, In, device=dev) * 0.1
+    rho = torch.randn(Out, In, device=dev) * 0.1 - 3
+    mb, rb = torch.randn(Out, device=dev) * 0.1, torch.randn(Out, device=dev) * 0.1 - 3
+    x = torch.randn(B, In, device=dev)
+    o, _ = F.fused_forward(x, mu, rho, mb, rb, flip=flip, S=S, seed=5, call=1, layer_id=2, packed=F.pack_params(mu, rho))
+    outs.append(o.flatten().cpu())
+torch.save(torch.cat(outs), sys.argv[1])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for tag, env in (("fast", {}), ("general", {"BT_FORCE_GENERIC": "1"})):
+        f = str(tmp_path / (tag + ".pt"))
+        subprocess.run([sys.executable, "-c", script, f], check=True, env=dict(os.environ, **env), timeout=300)
+        res.append(torch.load(f))
+    assert res[0].numel() == res[1].numel() and torch.isfinite(res[0]).all()
+    assert torch.equal(res[0], res[1])
