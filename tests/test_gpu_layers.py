@@ -107,6 +107,12 @@ def test_philox_mode_replays_through_oracle(name):
         else:
             ref = O.reparam_fwd_ref(g["x"], g["mu_w"], g["rho_w"], eps_w[s], g["mu_b"], g["rho_b"], eb, g["conv"])
         assert_close(out[s], ref, RTOL, ATOL, f"{name}[s={s}]")
+        from oracle import c_oracle as CO          # and the independent plain-C oracle (fp64 accumulation)
+        if flip:
+            refc = CO.flipout_fwd(g["x"], g["mu_w"], g["rho_w"], eps_w[s], s_in[s], s_out[s], g["mu_b"], g["rho_b"], eb, g["conv"])
+        else:
+            refc = CO.reparam_fwd(g["x"], g["mu_w"], g["rho_w"], eps_w[s], g["mu_b"], g["rho_b"], eb, g["conv"])
+        assert_close(out[s], refc, RTOL, ATOL, f"{name}[s={s}] vs C oracle")
     # sample identity is global: the same (sample0 + s) drawn in a different launch gives the same result
     out_b, _ = F.fused_forward(_cuda(g["x"]), _cuda(g["mu_w"]), _cuda(g["rho_w"]), _cuda(g["mu_b"]), _cuda(g["rho_b"]), flip=flip,
                                conv=g["conv"], S=1, seed=seed, call=call, layer_id=lid, sample0=s0 + 1)

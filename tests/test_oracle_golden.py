@@ -82,3 +82,17 @@ def test_get_rho():
     g = load_golden("get_rho")
     assert_close(O.get_rho_ref(g["w"], 0.1), g["rho_0p1"], rtol=1e-6, atol_scale=0)
     assert_close(O.get_rho_ref(g["w"], 0.5), g["rho_0p5"], rtol=1e-6, atol_scale=0)
+
+
+@pytest.mark.parametrize("name", [n for n in LAYER_FIX if "c3x16k7s2" not in n or True])
+def test_plain_c_oracle_matches_golden(name):
+    """The independent plain-C restatement (oracle/bt_oracle_c.c, fp64 accumulation) against the reference's outputs."""
+    from oracle import c_oracle as CO
+    g = layer_tensors(load_golden(name))
+    if "flipout" in name:
+        out = CO.flipout_fwd(g["x"], g["mu_w"], g["rho_w"], g["eps_w"], g["sign_in"], g["sign_out"], g["mu_b"], g["rho_b"], g["eps_b"], g["conv"])
+    else:
+        out = CO.reparam_fwd(g["x"], g["mu_w"], g["rho_w"], g["eps_w"], g["mu_b"], g["rho_b"], g["eps_b"], g["conv"])
+    assert_close(out, g["out"], rtol=2e-5, atol_scale=2e-6, what=name + ".out (C oracle)")
+    kl = CO.kl_layer(g["mu_w"], g["rho_w"], g["prior_mu_w"], g["prior_sigma_w"], g["mu_b"], g["rho_b"], g["prior_mu_b"], g["prior_sigma_b"])
+    assert abs(kl - float(g["kl"])) <= 2e-6 * abs(float(g["kl"])), (name, kl, float(g["kl"]))
