@@ -39,6 +39,7 @@ import torch.nn as nn
 import bayesian_torch.layers as RL                                   # the reference
 from bayesian_torch.models.dnn_to_bnn import dnn_to_bnn as ref_dnn_to_bnn, get_kl_loss as ref_get_kl_loss
 from bayesian_torch.utils.util import get_rho as ref_get_rho
+from bayesian_torch.utils import util as ref_util
 from bayesian_torch_amd.harness import resnet as H                    # plain-torch skeletons (ours)
 
 OUT = os.path.join(REPO, "tests", "golden")
@@ -191,6 +192,7 @@ def model_case(name, build, x_shape, btype, S, seed, store_full):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
     print("layer fixtures")
     for tag, ctor, xs, rp in LINEAR_CASES:
         layer_case("linear_reparam_" + tag, "LinearReparameterization", ctor, xs, random_priors=rp)
@@ -212,6 +214,13 @@ def main():
     w = torch.randn(257, generator=g) * 0.2
     w[0] = 0.0
     save("get_rho", dict(deltas=[0.1, 0.5]), w=npf(w), rho_0p1=npf(ref_get_rho(w, 0.1)), rho_0p5=npf(ref_get_rho(w, 0.5)))
+
+    print("uncertainty measures (utils/util.py:41-60)")
+    g = torch.Generator().manual_seed(31)
+    mc = torch.softmax(torch.randn(7, 9, 10, generator=g) * 2.0, -1).numpy().astype(np.float64)
+    save("uncertainty", dict(shape=[7, 9, 10]), mc_preds=mc.astype(np.float32), entropy=ref_util.entropy(mc.astype(np.float32)).astype(np.float32),
+         predictive_entropy=ref_util.predictive_entropy(mc.astype(np.float32)).astype(np.float32),
+         mutual_information=ref_util.mutual_information(mc.astype(np.float32)).astype(np.float32))
 
     print("negative paths")
     neg = []
