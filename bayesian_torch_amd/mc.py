@@ -56,3 +56,47 @@ def mc_forward(model, x, S, sample0=0, with_kl=True):
     if with_kl and ctx.kls:
         kl = torch.stack(ctx.kls).sum()
     return out, kl
+
+
+class McGraph:
+    """``mc_forward`` (+ the MC epilogue) captured once in a HIP graph and replayed per batch: the ~25 kernel launches of a
+    model become one graph launch.  The draws stay fresh: every fused kernel adds a device-side counter (``call_base``,
+    bt_rng.call_base_dev) to its baked-in ``call`` coordinate and the graph itself advances that counter by the number of
+    layer calls at its end -- replay r uses exactly the coordinates eager call r would have used.
+    ("capturing the whole model per sample in a HIP graph".)"""
+
+    def __init__(self, model, x, S, sample0=0, with_kl=True, epilogue=True):
+        from . import functional as F, rng
+        self.S, self.B = int(S), x.shape[0]
+        self.x = x.clone()
+        self.call_base = torch.zeros(1, dtype=torch.int32, device=x.device)
+
+        def run():
+            B = self.B
+            with torch.no_grad(), mc_samples(self.S, B, sample0, collect_kl=with_kl, call_base=self.call_base) as ctx:
+                out = model(self.x)
+            out = out[0] if isinstance(out, tuple) else out
+            logits = out.reshape(self.S, B, *out.shape[1:])
+            kl = torch.stack(ctx.kls).sum() if (with_kl and ctx.kls) else None
+            packed = F.mc_epilogue(logits.reshape(self.S, B, -1)) if epilogue else None
+            return logits, kl, packed
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up outside capture: parameter packs, workspaces, LDS attributes
+            run()
+            c0 = rng.peek_call()
+            run()
+            self.calls_per_run = rng.peek_call() - c0
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.logits, self.kl, self.packed = run()
+            self.call_base.add_(self.calls_per_run)
+
+    def replay(self, x=None):
+        """-> (logits [S, B, ...], kl, packed epilogue sums) -- tensors owned by the graph, overwritten by the next replay."""
+        if x is not None:
+            self.x.copy_(x)
+        self.graph.replay()
+        return self.logits, self.kl, self.packed

@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--samples", type=int, default=0, help="MC samples per GPU per step (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured HIP graph")
     ap.add_argument("--no-fuse", action="store_true", help="keep BatchNorm/ReLU/add as separate torch modules")
     ap.add_argument("--layers-json", default="", help="write the per-layer roofline table here")
     args = ap.parse_args()
@@ -132,12 +133,32 @@ def main():
     rng.set_mode("philox")
     rng.manual_seed(0)
 
-    def step(i):
+    def eager_step(i):
         logits, kl = mc_forward(net, x, S, sample0=(i * world + rank) * S, with_kl=True)
         packed = BF.mc_epilogue(logits.reshape(S, B, -1))
         buf = mc_dist.finish_pack(packed, kl, world)
         mc_dist.reduce_packed(buf)
         return buf
+
+    # Default: the step's kernels (21 fused forwards, pooling, epilogue) are captured once in a HIP graph; the draw counter
+    # lives on the device and advances per replay. The rank's sample ids are fixed at capture (sample0 = rank*S) and the
+    # per-step freshness comes from the call counter. The packed all-reduce stays outside the graph.
+    graph = None
+    if not args.no_graph:
+        try:
+            from bayesian_torch_amd.mc import McGraph
+            graph = McGraph(net, x, S, sample0=rank * S, with_kl=True, epilogue=True)
+        except Exception as e:  # noqa: BLE001 -- capture is an optimisation; report and fall back to eager launches
+            print(f"bench.py: HIP graph capture failed ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
+            graph = None
+
+    def graph_step(i):
+        _, kl, packed = graph.replay()
+        buf = mc_dist.finish_pack(packed, kl, world)
+        mc_dist.reduce_packed(buf)
+        return buf
+
+    step = graph_step if graph is not None else eager_step
 
     def barrier():
         torch.cuda.synchronize()
@@ -177,7 +198,7 @@ def main():
                 recs[n][-1][1] = e
             handles += [m.register_forward_pre_hook(pre), m.register_forward_hook(post)]
         for i in range(args.steps):
-            step(args.warmup + args.steps + i)
+            eager_step(args.warmup + args.steps + i)   # eager: module hooks do not run inside a captured graph
         torch.cuda.synchronize()
         for h in handles:
             h.remove()
@@ -218,7 +239,8 @@ def main():
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload=w["desc"], mc_samples_per_gpu_per_step=S, global_samples_per_step=S * world, batch=B,
                                 rng="on-chip philox", parallelism=f"mc{world}", kl="fused into forward kernels",
-                                output_stage="bn+relu+residual folded into conv epilogue" if fused else "separate torch modules"),
+                                output_stage="bn+relu+residual folded into conv epilogue" if fused else "separate torch modules",
+                                launch="hip graph replay" if graph is not None else "eager"),
                     roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:
