@@ -56,7 +56,7 @@ class FusedBayesLayer(BaseVariationalLayer_):
         self.register_buffer("post_scale", None, persistent=False)
         self.register_buffer("post_shift", None, persistent=False)
         self._sigma_cache = None   # ((versions, pointers), (mu_packed, sigma_packed)): a pure function of (mu, rho)
-        self.inject_draw = None   # test hook: dict(eps_w [S,*w], eps_b, sign_in, sign_out) consumed instead of a fresh draw
+        self.inject_draw = None   # test hook: dict(eps_w [S,*w], eps_b, sign_in, sign_out) consumed instead of a fresh draw (or a list of them)
         self.init_parameters()
         self.quant_prepare = False
 
@@ -112,6 +112,11 @@ class FusedBayesLayer(BaseVariationalLayer_):
         return c[1]
 
     def _conv_desc(self):
+        if getattr(self, "_one_d", False):       # Conv1d: a 1 x k kernel over a 1 x L image
+            one = lambda v: v[0] if isinstance(v, (tuple, list)) else v
+            if isinstance(self.padding, str):
+                raise NotImplementedError("string padding modes are not forwarded by dnn_to_bnn and not supported")
+            return dict(stride=(1, one(self.stride)), padding=(0, one(self.padding)), dilation=(1, one(self.dilation)), groups=self.groups)
         pad = self.padding
         if isinstance(pad, str):
             raise NotImplementedError("string padding modes are not forwarded by dnn_to_bnn and not supported")
@@ -138,7 +143,12 @@ class FusedBayesLayer(BaseVariationalLayer_):
                 x = x.reshape(-1, self.in_features)
             conv = None
         else:
-            if x.dim() != 4 or x.shape[1] != self.in_channels:
+            one_d = getattr(self, "_one_d", False)
+            if one_d:
+                if x.dim() != 3 or x.shape[1] != self.in_channels:
+                    raise RuntimeError(f"{type(self).__name__}: expected [N, {self.in_channels}, L], got {tuple(x.shape)}")
+                x = x.unsqueeze(2)
+            elif x.dim() != 4 or x.shape[1] != self.in_channels:
                 raise RuntimeError(f"{type(self).__name__}: expected [N, {self.in_channels}, H, W], got {tuple(x.shape)}")
             conv = self._conv_desc()
         if x.shape[0] == 0:
@@ -154,12 +164,17 @@ class FusedBayesLayer(BaseVariationalLayer_):
             else:
                 raise RuntimeError(f"inside mc_samples(S={S}, batch={ctx.batch}) a Bayesian layer got batch {x.shape[0]}")
         B = x.shape[0] // (1 if shared else S)
+        one_d = getattr(self, "_one_d", False)
+        mu_t, rho_t = self._w("mu"), self._w("rho")
+        if one_d:                      # [Co, Ci/g, k] -> [Co, Ci/g, 1, k] (views: same storage, autograd flows through)
+            mu_t, rho_t = mu_t.unsqueeze(2), rho_t.unsqueeze(2)
 
         sample0 = 0 if ctx is None else ctx.sample0
         call_base = None if ctx is None else ctx.call_base
         call, seed = rng.next_call(), rng.seed()
         if self.inject_draw is not None:
-            draw = {k: v for k, v in self.inject_draw.items() if v is not None}
+            inj = self.inject_draw.pop(0) if isinstance(self.inject_draw, list) else self.inject_draw   # a list feeds successive calls
+            draw = {k: v for k, v in inj.items() if v is not None}
             if draw["eps_w"].shape[0] != S:
                 raise RuntimeError(f"inject_draw holds {draw['eps_w'].shape[0]} samples, this call computes {S}")
         else:
@@ -176,14 +191,14 @@ class FusedBayesLayer(BaseVariationalLayer_):
                         packed=self._packed())
             if call_base is not None:
                 raise RuntimeError("graph-replayed draws (call_base) are not supported on the training path")
-            out = FusedForward.apply(x, self._w("mu"), self._w("rho"), self.mu_bias, self.rho_bias, opts)
+            out = FusedForward.apply(x, mu_t, rho_t, self.mu_bias, self.rho_bias, opts)
             kl = None
             if want_kl:
                 flat = [t for sg in self._kl_segments() for t in sg]
                 kl = KLNormal.apply(("layer", self._layer_id), *flat)
         else:
             priors = (self.prior_weight_mu, self.prior_weight_sigma, self.prior_bias_mu, self.prior_bias_sigma) if want_kl else None
-            out, kl = F.fused_forward(x, self._w("mu"), self._w("rho"), self.mu_bias, self.rho_bias, flip=self._flip, conv=conv,
+            out, kl = F.fused_forward(x, mu_t, rho_t, self.mu_bias, self.rho_bias, flip=self._flip, conv=conv,
                                       S=S, shared_x=shared, priors=priors, eps_w=draw.get("eps_w"), eps_b=draw.get("eps_b"),
                                       sign_in=draw.get("sign_in"), sign_out=draw.get("sign_out"), seed=seed, call=call,
                                       layer_id=self._layer_id, sample0=sample0, call_base=call_base, want_kl=want_kl,
@@ -193,6 +208,8 @@ class FusedBayesLayer(BaseVariationalLayer_):
                           x_shape=(B,) + tuple(x.shape[1:]), out_shape=(B,) + tuple(out.shape[1:]))
         if lead is not None:
             out = out.reshape(lead + (self.out_features,))
+        if one_d:
+            out = out.squeeze(2)
         if collect:
             ctx.kls.append(kl)
         return (out, kl) if return_kl else out
@@ -207,7 +224,7 @@ class FusedBayesLayer(BaseVariationalLayer_):
         if conv is None:
             os_ = (S, B, self.out_features)
         else:
-            kh, kw = eps_w_buf.shape[2], eps_w_buf.shape[3]
+            kh, kw = (1, eps_w_buf.shape[2]) if eps_w_buf.dim() == 3 else (eps_w_buf.shape[2], eps_w_buf.shape[3])
             os_ = (S, B, self.out_channels) + F.conv_out_hw(x.shape[2], x.shape[3], kh, kw, *conv["stride"], *conv["padding"], *conv["dilation"])
 
         def eps():

@@ -1,2 +1,3 @@
 from .linear_variational import *
 from .conv_variational import *
+from .rnn_variational import *

@@ -4,7 +4,7 @@
 from .._fused import FusedBayesLayer
 from ..base_variational_layer import get_kernel_size
 
-__all__ = ["Conv2dReparameterization"]
+__all__ = ["Conv2dReparameterization", "Conv1dReparameterization"]
 
 
 class Conv2dReparameterization(FusedBayesLayer):
@@ -25,6 +25,28 @@ class Conv2dReparameterization(FusedBayesLayer):
         self.bias = bias
         kh, kw = get_kernel_size(kernel_size, 2)
         self._build((out_channels, in_channels // groups, kh, kw), bias)
+
+    def forward(self, input, return_kl=True, residual=None):
+        return self._forward(input, return_kl, residual)
+
+
+class Conv1dReparameterization(FusedBayesLayer):
+    """Drop-in for reference ``conv_variational.py:68-232`` -- a 1 x k kernel over a 1 x L image on the same fused kernel."""
+    _kind, _flip, _wname, _one_d = "conv", False, "kernel", True
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 prior_mean=0, prior_variance=1, posterior_mu_init=0, posterior_rho_init=-3.0, bias=True):
+        super().__init__()
+        if in_channels % groups != 0 or out_channels % groups != 0:
+            raise ValueError('invalid in_channels size')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation, self.groups = kernel_size, stride, padding, dilation, groups
+        self.prior_mean, self.prior_variance = prior_mean, prior_variance
+        self.posterior_mu_init = (posterior_mu_init,)
+        self.posterior_rho_init = (posterior_rho_init,)
+        self.bias = bias
+        k = kernel_size[0] if isinstance(kernel_size, (tuple, list)) else kernel_size
+        self._build((out_channels, in_channels // groups, k), bias)
 
     def forward(self, input, return_kl=True, residual=None):
         return self._forward(input, return_kl, residual)

@@ -2,8 +2,7 @@
 
 Same contract: in-place recursive swap of leaf modules whose class name contains "Conv" /
 "Linear" by ``<ClassName><params['type']>`` looked up in ``bayesian_torch_amd.layers``
-(AttributeError when that class does not exist: Conv1d/3d/Transpose, LSTM are outside this
-build), same dict keys (KeyError when one is missing), MOPED initialisation, and
+(AttributeError when that class does not exist: Conv3d / ConvTranspose are outside this build), same dict keys (KeyError when one is missing), MOPED initialisation, and
 ``dnn_to_bnn_flag = True`` on every created layer.  ``get_kl_loss`` gathers every fused layer's
 (mu, rho, prior) tensors into ONE bt_kl_normal launch instead of ~12 ATen passes per layer.
 """
@@ -49,8 +48,14 @@ def bnn_conv_layer(params, d):
 
 
 def bnn_lstm_layer(params, d):
-    # same lookup as the reference; LSTM<type> does not exist in this build -> AttributeError
-    getattr(bayesian_layers, d.__class__.__name__ + params["type"])
+    layer_fn = getattr(bayesian_layers, d.__class__.__name__ + params["type"])
+    bnn_layer = layer_fn(in_features=d.input_size, out_features=d.hidden_size, prior_mean=params["prior_mu"],
+                         prior_variance=params["prior_sigma"], posterior_mu_init=params["posterior_mu_init"],
+                         posterior_rho_init=params["posterior_rho_init"], bias=d.bias is not None)
+    if params["moped_enable"]:
+        print("WARNING: MOPED method is not supported for LSTM layers!!!")
+    bnn_layer.dnn_to_bnn_flag = True
+    return bnn_layer.to(next(d.parameters()).device)
 
 
 def dnn_to_bnn(m, bnn_prior_parameters):

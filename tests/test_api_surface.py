@@ -84,8 +84,12 @@ def test_negative_paths_match_reference():
         dnn_to_bnn(nn.Sequential(nn.Linear(2, 2)), bad)
     with pytest.raises(AttributeError, match="LinearFoo"):
         dnn_to_bnn(nn.Sequential(nn.Linear(2, 2)), dict(PRIOR, type="Foo"))
-    with pytest.raises(AttributeError):       # LSTM layers are outside this build (the reference has LSTMReparameterization)
-        dnn_to_bnn(nn.Sequential(nn.LSTM(2, 2)), PRIOR)
+    with pytest.raises(AttributeError):       # Conv3d / ConvTranspose layers are outside this build
+        dnn_to_bnn(nn.Sequential(nn.Conv3d(2, 2, 3)), PRIOR)
+    seq = nn.Sequential(nn.LSTM(3, 5), nn.Conv1d(2, 4, 3))
+    dnn_to_bnn(seq, PRIOR)
+    assert repr(seq[0]) == "LSTMReparameterization(\n  (ih): LinearReparameterization()\n  (hh): LinearReparameterization()\n)"
+    assert repr(seq[1]) == "Conv1dReparameterization()" and tuple(seq[1].mu_kernel.shape) == (4, 2, 3)
     lay = L.LinearReparameterization(2, 2)
     with pytest.raises(ValueError, match="Unknown prior_type: xyz"):
         lay.kl_div(torch.ones(1), torch.ones(1), torch.ones(1), torch.ones(1), "xyz")

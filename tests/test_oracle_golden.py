@@ -96,3 +96,17 @@ def test_plain_c_oracle_matches_golden(name):
     assert_close(out, g["out"], rtol=2e-5, atol_scale=2e-6, what=name + ".out (C oracle)")
     kl = CO.kl_layer(g["mu_w"], g["rho_w"], g["prior_mu_w"], g["prior_sigma_w"], g["mu_b"], g["rho_b"], g["prior_mu_b"], g["prior_sigma_b"])
     assert abs(kl - float(g["kl"])) <= 2e-6 * abs(float(g["kl"])), (name, kl, float(g["kl"]))
+
+
+@pytest.mark.parametrize("name", ["conv1d_reparam_c6x10k3s2", "conv1d_flipout_c6x10k3s2"])
+def test_conv1d_goldens_through_oracle(name):
+    """Conv1d == Conv2d over a 1 x L image: the oracle reproduces the reference's Conv1d outputs that way."""
+    g = load_golden(name)
+    conv = dict(stride=(1, 2), padding=(0, 1), dilation=(1, 1), groups=1)
+    x4, w4 = g["x"].unsqueeze(2), lambda t: t.unsqueeze(2)
+    if "flipout" in name:
+        out = O.flipout_fwd_ref(x4, w4(g["mu_w"]), w4(g["rho_w"]), w4(g["eps_w"]), g["sign_in"].unsqueeze(2), g["sign_out"].unsqueeze(2),
+                                g["mu_b"], g["rho_b"], g["eps_b"], conv)
+    else:
+        out = O.reparam_fwd_ref(x4, w4(g["mu_w"]), w4(g["rho_w"]), w4(g["eps_w"]), g["mu_b"], g["rho_b"], g["eps_b"], conv)
+    assert_close(out.squeeze(2), g["out"], rtol=1e-5, atol_scale=1e-6, what=name)

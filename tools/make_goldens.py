@@ -17,6 +17,9 @@ SURVEY.md Appendix B.
     draw order and asserting the replayed eps equals the buffer.
 
 Usage:  python tools/make_goldens.py      (writes tests/golden/)
+(conv1d_*.npz, lstm_reparam_7x5.npz and uncertainty.npz were produced by the same recipe in an interactive session:
+Conv1d{Reparameterization,Flipout}(6, 10, 3, stride=2, padding=1) on x[3,6,17] with seeds 11/12/13 and return_kl=False;
+LSTMReparameterization(7, 5) on X[3,4,7] with seeds 21/22/23, per-step eps recovered by replaying the seeded draws.)
 """
 import json
 import os
