@@ -77,7 +77,7 @@ static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const flo
   a.do_kl = kl_out != nullptr;
   a.seed_lo = (uint32_t)d->rng.seed, a.seed_hi = (uint32_t)(d->rng.seed >> 32);
   if (ep) a.ep_scale = ep->scale, a.ep_shift = ep->shift, a.ep_res = ep->residual, a.ep_res_stride = ep->residual_sample_stride, a.ep_relu = ep->relu;
-  a.out_vec4 = (!linear && !a.pixel_major && a.HoWo > 1 && (a.HoWo & 3) == 0 && al16(out) && (!a.ep_res || (al16(a.ep_res) && (a.ep_res_stride & 3) == 0)) &&
+  a.out_vec4 = (!linear && !a.pixel_major && a.HoWo > 1 && (a.Wo & 3) == 0 && al16(out) && (!a.ep_res || (al16(a.ep_res) && (a.ep_res_stride & 3) == 0)) &&
                 (!d->sign_out || al16(d->sign_out))) ? 1 : 0;
   a.dbg = g_dbg;
   a.call = d->rng.call, a.call_base = d->rng.call_base_dev, a.layer_id = d->rng.layer_id, a.sample0 = d->rng.sample0;

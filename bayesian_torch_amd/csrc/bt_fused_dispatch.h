@@ -7,18 +7,45 @@
 
 namespace bt {
 
-// Can this launch run the specialised kernel (bt_fused_fast.h)?  Worst-case patch: every tap active.
+// Tile geometry of the specialised kernel (bt_fused_fast.h): t_NI images x t_R output rows x t_Wt output columns per tile,
+// chosen so the x patch of 4 channels (worst case: every tap active) fits the LDS x buffer. Returns false when this launch
+// has to run the general kernel.
 template <int BM, bool LINEAR>
-static bool fast_ok(const FwdArgs& a) {
+static bool fast_geometry(FwdArgs& a) {
   static const bool forced_off = getenv("BT_FORCE_GENERIC") != nullptr;  // A/B hook for tests and benchmarks
-  if (forced_off || !a.mu_pk || (((uintptr_t)a.mu_pk | (uintptr_t)a.sig_pk) & 15u) || a.T > kMaxTaps / 2 || a.w_elems >= (1ll << 29) || a.x_elems >= (1ll << 29)) return false;
-  if (LINEAR) return true;  // the LINEAR flavour is only dispatched when its float4 conditions hold
-  if (!(a.pixel_major || (a.HoWo <= BM && BM % a.HoWo == 0))) return false;
-  const int NI = a.pixel_major ? BM : BM / a.HoWo, R = a.pixel_major ? 1 : a.Ho, Wt = a.pixel_major ? 1 : a.Wo;
+  if (forced_off || !a.mu_pk || (((uintptr_t)a.mu_pk | (uintptr_t)a.sig_pk) & 15u) || a.T > kMaxTaps / 2 || a.w_elems >= (1ll << 29) ||
+      a.x_elems >= (1ll << 29))
+    return false;
+  constexpr long long XW = (long long)kBK * ((BM < 256 ? BM : 256) + 1);
   const int dys = (a.KH - 1) * a.DH, dxs = (a.KW - 1) * a.DW;
-  const long long PHt = (long long)(R - 1) * (dys ? a.SH : 1) + dys + 1, PWt = (long long)(Wt - 1) * (dxs ? a.SW : 1) + dxs + 1;
-  const long long PCH = NI * PHt * PWt;
-  return 4 * PCH <= (long long)kBK * ((BM < 256 ? BM : 256) + 1) && PCH < 65536;
+  auto fits = [&](int NI, int R, int Wt) {
+    const long long PHt = (long long)(R - 1) * (dys ? a.SH : 1) + dys + 1, PWt = (long long)(Wt - 1) * (dxs ? a.SW : 1) + dxs + 1;
+    const long long PCH = NI * PHt * PWt;
+    return 4 * PCH <= XW && PCH < 65536;
+  };
+  int NI, R, Wt;
+  if (LINEAR || a.HoWo == 1 || a.pixel_major) {
+    NI = BM, R = 1, Wt = 1;               // one output position per image: tile = BM images (pixel-major: of one pixel)
+    if (!LINEAR && !fits(NI, R, Wt)) return false;
+  } else if (a.HoWo <= BM) {
+    NI = BM / a.HoWo, R = a.Ho, Wt = a.Wo;  // whole images
+    while (NI > 1 && !fits(NI, R, Wt)) --NI;
+    if (!fits(NI, R, Wt)) return false;
+  } else if (a.Wo <= BM) {
+    NI = 1, R = BM / a.Wo, Wt = a.Wo;       // a band of rows of one image
+    while (R > 1 && !fits(NI, R, Wt)) --R;
+    if (!fits(NI, R, Wt)) return false;
+  } else {
+    NI = 1, R = 1, Wt = BM;                 // a segment of one row
+    if (!fits(NI, R, Wt)) return false;
+  }
+  const bool grid = a.pixel_major || (!LINEAR && a.HoWo > 1);
+  a.t_NI = NI, a.t_R = R, a.t_Wt = Wt;
+  a.n_bt = (a.B + NI - 1) / NI;
+  a.n_rt = grid ? (a.Ho + R - 1) / R : 1;
+  a.n_ct = grid ? (a.Wo + Wt - 1) / Wt : 1;
+  a.m_tiles = a.n_bt * a.n_rt * a.n_ct;
+  return true;
 }
 
 template <typename Kern>
@@ -38,20 +65,24 @@ static int launch_cfg(FwdArgs& a, hipStream_t stream) {
   constexpr int lds = fused_lds_bytes<BN, BM, FLIP>();
   static_assert(lds <= 160 * 1024, "LDS budget of one CU");
   a.n_tiles = (a.Cog + BN - 1) / BN;
-  if (a.pixel_major) {
-    a.mt_per_pixel = (a.B + BM - 1) / BM;
-    a.m_tiles = a.HoWo * a.mt_per_pixel;
-  } else {
-    a.mt_per_pixel = 1;
-    a.m_tiles = (a.M + BM - 1) / BM;
+  bool fast = false;
+  if constexpr (!INJ) fast = fast_geometry<BM, LINEAR>(a);  // injected draws are the parity/debug mode: always the general kernel
+  if (!fast) {  // general kernel: BM consecutive (b, ho, wo), or pixel-major
+    if (a.pixel_major) {
+      a.mt_per_pixel = (a.B + BM - 1) / BM;
+      a.m_tiles = a.HoWo * a.mt_per_pixel;
+    } else {
+      a.mt_per_pixel = 1;
+      a.m_tiles = (a.M + BM - 1) / BM;
+    }
+    a.patch_ok = (!LINEAR && (a.pixel_major || (a.HoWo <= BM && BM % a.HoWo == 0))) ? 1 : 0;
   }
-  a.patch_ok = (!LINEAR && (a.pixel_major || (a.HoWo <= BM && BM % a.HoWo == 0))) ? 1 : 0;
   const long long total = (long long)a.G * a.n_tiles * a.S * a.m_tiles;
   if (total <= 0 || total > 0x7FFFFFFFll) return set_error(BT_ERR_UNSUPPORTED, "fused forward: grid too large");
   a.total_blocks = (int)total;
   a.kl_slices = total < 256 ? (int)total : 256;  // workgroups that sweep a slice of the weights for KL (4 wave slots each)
-  if constexpr (!INJ) {  // injected draws are the parity/debug mode: always the general kernel
-    if (fast_ok<BM, LINEAR>(a)) {
+  if constexpr (!INJ) {
+    if (fast) {
       auto fk = fused_fast_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, false>;
       static bool fflags[64] = {};
       if (int rc = ensure_lds(fk, lds, fflags)) return rc;
@@ -72,7 +103,8 @@ static int launch_cfg(FwdArgs& a, hipStream_t stream) {
 
 static inline long long tiles_for(const FwdArgs& a, int BN, int BM) {
   const long long nt = (a.Cog + BN - 1) / BN;
-  const long long mt = a.pixel_major ? (long long)a.HoWo * ((a.B + BM - 1) / BM) : (a.M + BM - 1) / BM;
+  long long mt = a.pixel_major ? (long long)a.HoWo * ((a.B + BM - 1) / BM) : (a.M + BM - 1) / BM;
+  if (!a.pixel_major && a.HoWo > 1 && a.HoWo <= BM) mt = (a.B + BM / a.HoWo - 1) / (BM / a.HoWo);  // whole-image tiles
   return (long long)a.G * nt * a.S * mt;
 }
 
@@ -90,8 +122,9 @@ static int pick_tile(FwdArgs& a, hipStream_t stream) {
     if constexpr (!LINEAR && !INJ) {  // 512-wide: fast flavour only (x as a patch); halves the weight-synthesis work per MFMA
       if (Mdom >= 512 && a.Cog <= 64 && tiles_for(a, 64, 512) >= kCUs) {
         FwdArgs probe = a;
-        probe.patch_ok = 1;
-        if (fast_ok<512, false>(probe)) return launch_cfg<64, 512, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
+        // only when the wide tile is actually filled (a 256-pixel image whose 2-image patch does not fit would leave half of it dead)
+        if (fast_geometry<512, false>(probe) && probe.t_NI * probe.t_R * probe.t_Wt >= 448)
+          return launch_cfg<64, 512, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
       }
     }
     if (Mdom >= 256 && a.Cog > 64 && tiles_for(a, 128, 256) >= kCUs) return launch_cfg<128, 256, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);

@@ -44,10 +44,24 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
   const int nt = L % a.n_tiles;
   const int g = L / a.n_tiles;
   const int n0 = nt * BN;
+  // Tile geometry (host: bt_fused_dispatch.h): a tile is t_NI images x t_R output rows x t_Wt output columns starting at
+  // (b0, r0, w0). Whole images (small feature maps), row bands of one image (ImageNet-size maps) and single pixels x BM
+  // images (pixel-major) are all this form; tile column ml = (img * t_R + r) * t_Wt + w, columns >= Mt are dead.
   const bool pix = a.pixel_major != 0;
-  const int tile_p = pix ? mt / a.mt_per_pixel : 0;
-  const int m0 = pix ? (mt - tile_p * a.mt_per_pixel) * BM : mt * BM;
-  const int m_lim = pix ? a.B : a.M;
+  const int t_NI = a.t_NI, t_R = a.t_R, t_Wt = a.t_Wt, RW = t_R * t_Wt, Mt = t_NI * RW;
+  const int bt = mt % a.n_bt, trest = mt / a.n_bt;
+  const int ct = trest % a.n_ct, rt = trest / a.n_ct;
+  const int b0 = bt * t_NI, r0 = rt * t_R, w0 = ct * t_Wt;
+  const int m0 = b0;  // Linear: first row of the tile
+  const uint32_t inv_rw = RW > 1 ? (uint32_t)((0x100000000ull + (unsigned)RW - 1) / (unsigned)RW) : 0u;  // exact for ml < 2^16
+  const uint32_t inv_wt = t_Wt > 1 ? (uint32_t)((0x100000000ull + (unsigned)t_Wt - 1) / (unsigned)t_Wt) : 0u;
+  auto col_decode = [&](int ml, int& b, int& ho, int& wo) -> bool {  // tile column -> output coordinates; false: dead column
+    const int img = RW == 1 ? ml : (int)__umulhi((uint32_t)ml, inv_rw);
+    const int rem = ml - img * RW;
+    const int r = t_Wt == 1 ? rem : (int)__umulhi((uint32_t)rem, inv_wt);
+    b = b0 + img, ho = r0 + r, wo = w0 + (rem - r * t_Wt);
+    return ml < Mt && b < a.B && ho < a.Ho && wo < a.Wo;
+  };
   const uint32_t sample = a.sample0 + (uint32_t)s;
   const int K = a.K, T = a.T, Cig = a.Cig;
 
@@ -74,9 +88,8 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
       e = make_int4(0, kh * a.DH, kw * a.DW, lane);
       if (LINEAR) {
         act = true;
-      } else if (pix) {
-        const int ho = tile_p / a.Wo, wo = tile_p - ho * a.Wo;
-        act = (unsigned)(ho * a.SH - a.PH + e.y) < (unsigned)a.H && (unsigned)(wo * a.SW - a.PW + e.z) < (unsigned)a.W;
+      } else if (pix) {  // the tile is one output pixel (r0, w0)
+        act = (unsigned)(r0 * a.SH - a.PH + e.y) < (unsigned)a.H && (unsigned)(w0 * a.SW - a.PW + e.z) < (unsigned)a.W;
       } else {
         const int lo_h = a.PH - e.y, lo_w = a.PW - e.z;
         const int hc = lo_h > 0 ? (lo_h + a.SH - 1) / a.SH : 0, wc = lo_w > 0 ? (lo_w + a.SW - 1) / a.SW : 0;
@@ -104,7 +117,6 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
   const int Cig4 = (Cig + 3) & ~3;
   // patch geometry (see bt_fused_fwd.h)
   const int dymin = misc[2], dymax = misc[3], dxmin = misc[4], dxmax = misc[5];
-  const int t_R = pix ? 1 : a.Ho, t_Wt = pix ? 1 : a.Wo, t_NI = pix ? BM : BM / a.HoWo;
   const int ps_h = (dymax == dymin) ? 1 : a.SH, gs_h = (dymax == dymin) ? a.SH : 1;
   const int ps_w = (dxmax == dxmin) ? 1 : a.SW, gs_w = (dxmax == dxmin) ? a.SW : 1;
   const int PHt = (t_R - 1) * ps_h + (dymax - dymin) + 1, PWt = (t_Wt - 1) * ps_w + (dxmax - dxmin) + 1;
@@ -186,8 +198,7 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
     if (!LINEAR) {
       const uint32_t inv_pimg = (uint32_t)((0x100000000ull + (unsigned)PIMG - 1) / (unsigned)PIMG);
       const uint32_t inv_pw = (uint32_t)((0x100000000ull + (unsigned)PWt - 1) / (unsigned)PWt);
-      const int y_lo = (pix ? (tile_p / a.Wo) * a.SH : 0) - a.PH + dymin, x_lo = (pix ? (tile_p % a.Wo) * a.SW : 0) - a.PW + dxmin;
-      const int b0 = pix ? m0 : m0 / a.HoWo;
+      const int y_lo = r0 * a.SH - a.PH + dymin, x_lo = w0 * a.SW - a.PW + dxmin;  // input coordinates of the patch origin
 #pragma unroll
       for (int i = 0; i < PPOS; ++i) {
         const int pos = ptid + kProducers * i;
@@ -424,9 +435,9 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
       if (LINEAR) {
         colbase[j] = ml;
       } else {
-        const int img = pix ? ml : ml / a.HoWo, p = pix ? 0 : ml - img * a.HoWo;
-        const int ho = p / a.Wo, wo = p - ho * a.Wo;
-        colbase[j] = img * PIMG + ho * ps_h * PWt + wo * ps_w;
+        int b, ho, wo;
+        const bool live = col_decode(ml, b, ho, wo);
+        colbase[j] = live ? (b - b0) * PIMG + (ho - r0) * ps_h * PWt + (wo - w0) * ps_w : 0;
       }
     }
     __syncthreads();  // stage 0 staged, rowtab written
@@ -525,26 +536,25 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
     if (TRANS && a.out_vec4) {
       // spatial NCHW output through the D[m][co] orientation: a lane owns ONE output channel (bias / scale / shift are lane
       // constants) and registers 4q..4q+3 are 4 consecutive output positions -> one 16-byte store (and residual load) per 4
-      // values. The host guarantees Ho*Wo % 4 == 0 and 16-byte aligned tensors, so a quad never straddles an image.
+      // values. The host guarantees Wo % 4 == 0 (tile widths are multiples of 4) and 16-byte aligned tensors: a quad stays in one row.
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int ml = m0 + wm * WTM + j * 32 + 8 * q + 4 * lh;
-          const int bq = ml / a.HoWo, pq = ml - bq * a.HoWo;
-          const bool mok = ml < m_lim;
+          int bq, hq, wq;
+          const bool mok = col_decode(wm * WTM + j * 32 + 8 * q + 4 * lh, bq, hq, wq);  // t_Wt % 4 == 0: the quad stays in one row
 #pragma unroll
           for (int i = 0; i < TN; ++i) {
             const int co_l = wn * WTN + i * 32 + li;
             const bool ok = mok && n0 + co_l < a.Cog;
-            const uint32_t oidx = ok ? (uint32_t)((bq * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + pq) : 0u;
-            const float b0 = bias0[co_l], sc = osc[co_l], sh = osh[co_l];
+            const uint32_t oidx = ok ? (uint32_t)(((bq * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hq) * a.Wo + wq) : 0u;
+            const float bs = bias0[co_l], sc = osc[co_l], sh = osh[co_l];
             float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (res_s) r4 = *reinterpret_cast<const float4*>(res_s + oidx);
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              v[e] = __fadd_rn(acc[0][i][j][4 * q + e], b0);
+              v[e] = __fadd_rn(acc[0][i][j][4 * q + e], bs);
               if constexpr (FLIP) {
                 const float so = INJ ? sout_s[oidx + e] : hash_sign(skey_out, oidx + e);
                 v[e] = __fadd_rn(v[e], __fmul_rn(__fadd_rn(acc[NW - 1][i][j][4 * q + e], bias1[co_l]), so));
@@ -561,37 +571,30 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
     } else {
   #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        int b_col = 0, p_col = tile_p;
-        if (!TRANS) {
-          const int ml = m0 + wm * WTM + j * 32 + li;
-          if (pix) {
-            b_col = ml;
-          } else {
-            b_col = ml / a.HoWo;
-            p_col = ml - b_col * a.HoWo;
-          }
-        }
-  #pragma unroll
+        int b_col = 0, h_col = 0, w_col = 0;
+        bool live_col = false;
+        if (!TRANS) live_col = col_decode(wm * WTM + j * 32 + li, b_col, h_col, w_col);  // lanes run along the tile columns
+#pragma unroll
         for (int i = 0; i < TN; ++i) {
           uint32_t oi[16];
           bool okv[16];
           int col[16];
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            int co_l, ml;
+            int co_l;
+            bool live;
+            int bb = b_col, hh = h_col, ww = w_col;
             if (TRANS) {
               co_l = wn * WTN + i * 32 + li;
-              ml = m0 + wm * WTM + j * 32 + row;
-              oi[r] = (uint32_t)((ml * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + tile_p);
+              live = col_decode(wm * WTM + j * 32 + row, bb, hh, ww);
             } else {
               co_l = wn * WTN + i * 32 + row;
-              ml = m0 + wm * WTM + j * 32 + li;
-              oi[r] = (uint32_t)((b_col * a.Co + g * a.Cog + n0 + co_l) * a.HoWo + p_col);
+              live = live_col;
             }
-            okv[r] = n0 + co_l < a.Cog && ml < m_lim;
+            okv[r] = live && n0 + co_l < a.Cog;
             col[r] = co_l;
-            if (!okv[r]) oi[r] = 0u;
+            oi[r] = okv[r] ? (uint32_t)(((bb * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hh) * a.Wo + ww) : 0u;
           }
           float rsd[16], so[FLIP ? 16 : 1];
           if (res_s) {

@@ -49,6 +49,7 @@ struct FwdArgs {
   int B, Ci, H, W, Co, KH, KW, SH, SW, PH, PW, DH, DW, G;
   int Ho, Wo, HoWo, M, K, Cig, Cog, S, T, HW;
   int n_tiles, m_tiles, total_blocks;
+  int t_NI, t_R, t_Wt, n_bt, n_rt, n_ct;  // fast flavour: tile = t_NI images x t_R rows x t_Wt cols; tile grid per (n-tile, sample)
   int patch_ok;                   // host: tiles are whole images (or pixel-major), so the x operand can be staged as a patch
   int pixel_major, mt_per_pixel;  // m-tile = (one output pixel, BM images) instead of BM consecutive (b, ho, wo)
   int w_vec, x_vec;               // float4 paths allowed (taps == 1, K % 4 == 0, 16-B aligned bases)

@@ -255,3 +255,40 @@ def test_lstm_reparameterization_matches_reference_golden():
     assert_close(cs.cpu(), g["c_ts"], RTOL, ATOL, "c_ts")
     assert_close(kl.cpu(), g["kl"], 1e-5, 0, "kl")
     assert_close(lstm.kl_loss().cpu(), g["kl_loss"], 1e-5, 0, "kl_loss")
+
+
+@pytest.mark.parametrize("Ci,Co,k,st,pd,H,W,B,flip", [
+    (8, 16, 3, 1, 1, 7, 7, 11, False),      # 49 pixels: whole-image tiles that do not divide the tile width
+    (8, 16, 3, 1, 1, 14, 14, 3, True),      # 196 pixels: one image per tile
+    (4, 8, 3, 1, 1, 30, 30, 2, False),      # 900 pixels: row bands of one image
+    (4, 8, 3, 2, 1, 45, 37, 2, False),      # stride 2, odd sizes, bands
+    (4, 8, 1, 1, 0, 1, 300, 2, False),      # one row wider than a tile: row segments
+    (3, 8, 7, 2, 3, 56, 56, 2, False),      # 7x7 stem on a larger image
+    (12, 8, 3, 1, 2, 20, 24, 2, True),      # padding 2 (wide halo), Wo % 4 == 0
+])
+def test_fast_kernel_tile_geometries_vs_oracle(Ci, Co, k, st, pd, H, W, B, flip):
+    """Spatial sizes that exercise every tile form of the specialised kernel (whole images / row bands / row segments,
+    dead columns, odd widths -> scalar stores, Wo % 4 == 0 -> float4 stores): on-chip draws replayed through the oracle."""
+    from oracle import bt_oracle as O
+    from bayesian_torch_amd import functional as F
+    gen = torch.Generator().manual_seed(Ci * 100 + H)
+    mu = torch.randn(Co, Ci, k, k, generator=gen) * 0.1
+    rho = torch.randn(Co, Ci, k, k, generator=gen) * 0.1 - 3
+    mb, rb = torch.randn(Co, generator=gen) * 0.1, torch.randn(Co, generator=gen) * 0.1 - 3
+    x = torch.randn(B, Ci, H, W, generator=gen)
+    conv = dict(stride=(st, st), padding=(pd, pd), dilation=(1, 1), groups=1)
+    S, seed, call, lid, s0 = 2, 77, 3, 9, 1
+    dev = torch.device("cuda")
+    out, _ = F.fused_forward(x.cuda(), mu.cuda(), rho.cuda(), mb.cuda(), rb.cuda(), flip=flip, conv=conv, S=S, seed=seed, call=call,
+                             layer_id=lid, sample0=s0, packed=F.pack_params(mu.cuda(), rho.cuda()))
+    out = out.reshape((S, B) + tuple(out.shape[1:])).cpu()
+    eps_w = F.rng_fill_normal(seed, call, lid, s0, 0, S, mu.shape, dev).cpu()
+    eps_b = F.rng_fill_normal(seed, call, lid, s0, 1, S, (Co,), dev).cpu()
+    for s in range(S):
+        if flip:
+            s_in = F.rng_fill_sign(seed, call, lid, s0, 2, S, x.shape, dev).cpu()
+            s_out = F.rng_fill_sign(seed, call, lid, s0, 3, S, out.shape[1:], dev).cpu()
+            ref = O.flipout_fwd_ref(x, mu, rho, eps_w[s], s_in[s], s_out[s], mb, rb, eps_b[s], conv)
+        else:
+            ref = O.reparam_fwd_ref(x, mu, rho, eps_w[s], mb, rb, eps_b[s], conv)
+        assert_close(out[s], ref, RTOL, ATOL, f"sample {s}")

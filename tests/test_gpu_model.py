@@ -221,3 +221,34 @@ def test_mc_graph_replay_matches_eager_and_draws_fresh_samples():
     rng.set_call(base + g.calls_per_run)
     e1, _ = mc_forward(net, x, 3, sample0=4)
     assert torch.equal(e1, l2)
+
+
+@pytest.mark.parametrize("btype", ["Reparameterization", "Flipout"])
+def test_resnet50_topology_cfg5_shape_family(btype):
+    """cfg5's model family (Bottleneck ResNet50: 1x1 / 3x3-stride-2 / 7x7 stem, ImageNet-style 64x64 inputs here) at small
+    width: on-chip draws replayed through the oracle, MC-batched."""
+    from oracle import bt_oracle as O
+    from bayesian_torch_amd import rng
+    from bayesian_torch_amd.harness import resnet as H
+    from bayesian_torch_amd.mc import mc_forward
+    from bayesian_torch_amd.models.dnn_to_bnn import dnn_to_bnn
+    torch.manual_seed(2)
+    ref = H.resnet50(10, width=8)
+    O.ref_dnn_to_bnn(ref, btype)
+    H.fill_bayes_params(ref, 4)
+    net = H.resnet50(10, width=8)
+    dnn_to_bnn(net, dict(PRIOR, type=btype))
+    H.fill_bayes_params(net, 4)
+    ref, net = ref.eval(), net.cuda().eval()
+    x = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(9))
+    rng.set_mode("philox")
+    rng.manual_seed(5)
+    S = 2
+    logits, kl = mc_forward(net, x.cuda(), S)
+    draws = [m.materialize_last_draw() for _, m in H.bayes_layers(net)]
+    with torch.no_grad():
+        for s in range(S):
+            for (_, rm), d in zip(H.bayes_layers(ref), draws):
+                rm.inject = {k: v[s].cpu() for k, v in d.items()}
+            assert_close(logits[s].cpu(), ref(x), 2e-4, 2e-5, f"resnet50 {btype} sample {s}")
+    assert_close(kl.cpu(), O.ref_get_kl_loss(ref), 1e-5, 0, "kl")
