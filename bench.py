@@ -40,6 +40,8 @@ WORKLOADS = {
                  net=lambda: H.resnet18(10, 64), x=(128, 3, 32, 32), btype="Reparameterization", S=32),
     "cfg4": dict(desc="cfg4: Bayesian-ResNet18 Flipout (Conv2dFlipout/LinearFlipout), CIFAR 3x32x32, batch=128",
                  net=lambda: H.resnet18(10, 64), x=(128, 3, 32, 32), btype="Flipout", S=32),
+    "cfg5": dict(desc="cfg5: Bayesian-ResNet50 Reparameterization, ImageNet 3x224x224, batch=256 (128 MC samples / 8 GPUs = 16 per GPU)",
+                 net=lambda: H.resnet50(1000, 64), x=(256, 3, 224, 224), btype="Reparameterization", S=16),
     "cfg2": dict(desc="cfg2: MLP 3072->512->10 (LinearReparameterization), batch=256",
                  net=lambda: H.mlp((3072, 512, 10)), x=(256, 3072), btype="Reparameterization", S=8),
 }
@@ -234,7 +236,10 @@ def main():
 
     if rank == 0:
         total = S * world * args.steps
-        line = dict(metric="MC-samples/sec (forward+KL), Bayesian-ResNet18 CIFAR batch=128", value=round(total / dt, 2), unit="MC-samples/s",
+        metric = "MC-samples/sec (forward+KL), Bayesian-ResNet18 CIFAR batch=128"      # BASELINE.json (cfg3, and cfg4 = its Flipout variant)
+        if args.workload in ("cfg2", "cfg5"):
+            metric = "MC-samples/sec (forward+KL), " + w["desc"]
+        line = dict(metric=metric, value=round(total / dt, 2), unit="MC-samples/s",
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4),
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload=w["desc"], mc_samples_per_gpu_per_step=S, global_samples_per_step=S * world, batch=B,
