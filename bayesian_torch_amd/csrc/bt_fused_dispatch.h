@@ -16,7 +16,7 @@ static bool fast_geometry(FwdArgs& a) {
   if (forced_off || !a.mu_pk || (((uintptr_t)a.mu_pk | (uintptr_t)a.sig_pk) & 15u) || a.T > kMaxTaps / 2 || a.w_elems >= (1ll << 29) ||
       a.x_elems >= (1ll << 29))
     return false;
-  constexpr long long XW = (long long)kBK * ((BM < 256 ? BM : 256) + 1);
+  constexpr long long XW = x_words<BM>();
   const int dys = (a.KH - 1) * a.DH, dxs = (a.KW - 1) * a.DW;
   auto fits = [&](int NI, int R, int Wt) {
     const long long PHt = (long long)(R - 1) * (dys ? a.SH : 1) + dys + 1, PWt = (long long)(Wt - 1) * (dxs ? a.SW : 1) + dxs + 1;

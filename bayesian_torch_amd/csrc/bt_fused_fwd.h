@@ -71,10 +71,16 @@ __device__ __forceinline__ int xcd_remap(int orig, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
+// Words of one LDS x buffer. Tiles up to 256 columns hold kBK im2col rows; the 512-wide tile (fast flavour only) stages x
+// as a patch and gets room for the 2-image 7x7/s2 stem patch of 32x32 inputs (4 x 2 x 37 x 37 words).
+template <int BM>
+constexpr int x_words() {
+  return kBK * ((BM <= 256 ? BM : 320) + 1);
+}
+
 template <int BN, int BM, bool FLIP>
 constexpr int fused_lds_bytes() {
-  // the x tile never needs more than 256 columns' worth: wider tiles (fast flavour only) stage x as a patch
-  return (2 * (FLIP ? 2 : 1) * (kBK * (BN + 1) + kBK * ((BM < 256 ? BM : 256) + 1)) + kMaxTaps * 4 + 24 + 8 + 80) * 4;
+  return (2 * (FLIP ? 2 : 1) * (kBK * (BN + 1) + x_words<BM>()) + kMaxTaps * 4 + 24 + 8 + 80) * 4;
 }
 
 __device__ __forceinline__ double block_sum_all(double v, double* scratch) {  // 12 waves; result in thread 0
