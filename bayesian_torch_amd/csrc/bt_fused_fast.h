@@ -37,20 +37,22 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
   const int cw = wave & 3, wn = cw / CWM, wm = cw % CWM;
 
   int L = xcd_remap(blockIdx.x, a.total_blocks);
-  const int mt = L % a.m_tiles;
+  // Integer division runs on the vector ALU even for uniform operands; readfirstlane brings the tile coordinates back to
+  // scalar registers so everything derived from them (base pointers, buffer descriptors, loop bounds) stays scalar.
+  const int mt = __builtin_amdgcn_readfirstlane(L % a.m_tiles);
   L /= a.m_tiles;
-  const int s = L % a.S;
+  const int s = __builtin_amdgcn_readfirstlane(L % a.S);
   L /= a.S;
-  const int nt = L % a.n_tiles;
-  const int g = L / a.n_tiles;
+  const int nt = __builtin_amdgcn_readfirstlane(L % a.n_tiles);
+  const int g = __builtin_amdgcn_readfirstlane(L / a.n_tiles);
   const int n0 = nt * BN;
   // Tile geometry (host: bt_fused_dispatch.h): a tile is t_NI images x t_R output rows x t_Wt output columns starting at
   // (b0, r0, w0). Whole images (small feature maps), row bands of one image (ImageNet-size maps) and single pixels x BM
   // images (pixel-major) are all this form; tile column ml = (img * t_R + r) * t_Wt + w, columns >= Mt are dead.
   const bool pix = a.pixel_major != 0;
   const int t_NI = a.t_NI, t_R = a.t_R, t_Wt = a.t_Wt, RW = t_R * t_Wt, Mt = t_NI * RW;
-  const int bt = mt % a.n_bt, trest = mt / a.n_bt;
-  const int ct = trest % a.n_ct, rt = trest / a.n_ct;
+  const int bt = __builtin_amdgcn_readfirstlane(mt % a.n_bt), trest = mt / a.n_bt;
+  const int ct = __builtin_amdgcn_readfirstlane(trest % a.n_ct), rt = __builtin_amdgcn_readfirstlane(trest / a.n_ct);
   const int b0 = bt * t_NI, r0 = rt * t_R, w0 = ct * t_Wt;
   const int m0 = b0;  // Linear: first row of the tile
   const uint32_t inv_rw = RW > 1 ? (uint32_t)((0x100000000ull + (unsigned)RW - 1) / (unsigned)RW) : 0u;  // exact for ml < 2^16
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
     if (lane == 0) misc[0] = __popcll(mask), misc[2] = dy0, misc[3] = dy1, misc[4] = dx0, misc[5] = dx1;
   }
   __syncthreads();
-  const int nA = misc[0];  // 0 only for degenerate geometry (no tap ever reaches data): outputs are the bias alone
+  const int nA = __builtin_amdgcn_readfirstlane(misc[0]);  // 0 only for degenerate geometry (no tap ever reaches data): outputs are the bias alone
 
   // ---- stage shape: CC channels x nA taps <= kBK rows --------------------------------------------------------------------
   const int NA = nA < 9 ? nA : 9;                       // taps per stage
@@ -116,7 +118,8 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
   while (CC > 4 && CC / 2 >= Cig) CC >>= 1;
   const int Cig4 = (Cig + 3) & ~3;
   // patch geometry (see bt_fused_fwd.h)
-  const int dymin = misc[2], dymax = misc[3], dxmin = misc[4], dxmax = misc[5];
+  const int dymin = __builtin_amdgcn_readfirstlane(misc[2]), dymax = __builtin_amdgcn_readfirstlane(misc[3]);
+  const int dxmin = __builtin_amdgcn_readfirstlane(misc[4]), dxmax = __builtin_amdgcn_readfirstlane(misc[5]);
   const int ps_h = (dymax == dymin) ? 1 : a.SH, gs_h = (dymax == dymin) ? a.SH : 1;
   const int ps_w = (dxmax == dxmin) ? 1 : a.SW, gs_w = (dxmax == dxmin) ? a.SW : 1;
   const int PHt = (t_R - 1) * ps_h + (dymax - dymin) + 1, PWt = (t_Wt - 1) * ps_w + (dxmax - dxmin) + 1;

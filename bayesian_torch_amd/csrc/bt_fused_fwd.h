@@ -123,15 +123,16 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
   const int cw = wave & 3, wn = cw / CWM, wm = cw % CWM;
 
   int L = xcd_remap(blockIdx.x, a.total_blocks);
-  const int mt = L % a.m_tiles;
+  // (uniform integer division runs on the vector ALU: readfirstlane returns the tile coordinates to scalar registers)
+  const int mt = __builtin_amdgcn_readfirstlane(L % a.m_tiles);
   L /= a.m_tiles;
-  const int s = L % a.S;
+  const int s = __builtin_amdgcn_readfirstlane(L % a.S);
   L /= a.S;
-  const int nt = L % a.n_tiles;
-  const int g = L / a.n_tiles;
+  const int nt = __builtin_amdgcn_readfirstlane(L % a.n_tiles);
+  const int g = __builtin_amdgcn_readfirstlane(L / a.n_tiles);
   const int n0 = nt * BN;
   const bool pix = a.pixel_major != 0;
-  const int tile_p = pix ? mt / a.mt_per_pixel : 0;                    // pixel-major: the tile's output pixel
+  const int tile_p = pix ? __builtin_amdgcn_readfirstlane(mt / a.mt_per_pixel) : 0;                   // pixel-major: the tile's output pixel
   const int m0 = pix ? (mt - tile_p * a.mt_per_pixel) * BM : mt * BM;  // first image (pixel-major) / first m
   const int m_lim = pix ? a.B : a.M;
   const uint32_t sample = a.sample0 + (uint32_t)s;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
     if (lane == 0) misc[0] = base, misc[2] = dy0, misc[3] = dy1, misc[4] = dx0, misc[5] = dx1;
   }
   __syncthreads();
-  const int nA = misc[0];
+  const int nA = __builtin_amdgcn_readfirstlane(misc[0]);
 
   // ---- stage schedule: (CC channels) x (NA active taps) <= kBK rows -------------------------------------------------
   int NA, CC;
@@ -208,7 +209,8 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
   // touch is staged ONCE per channel (zero halo included) and the consumers address it as base(lane's output pixel) +
   // offset(tap) + channel*plane -- instead of an im2col tile that re-gathers each pixel once per tap. 6-9x fewer load
   // instructions for 3x3 kernels (the texture addresser needs 16 cycles per 64-lane dword load, coalesced or not).
-  const int dymin = misc[2], dymax = misc[3], dxmin = misc[4], dxmax = misc[5];
+  const int dymin = __builtin_amdgcn_readfirstlane(misc[2]), dymax = __builtin_amdgcn_readfirstlane(misc[3]);
+  const int dxmin = __builtin_amdgcn_readfirstlane(misc[4]), dxmax = __builtin_amdgcn_readfirstlane(misc[5]);
   const int t_R = pix ? 1 : a.Ho, t_Wt = pix ? 1 : a.Wo;            // output rows / cols of one image inside the tile
   const int t_NI = pix ? BM : BM / a.HoWo;                            // images per tile
   const int ps_h = (dymax == dymin) ? 1 : a.SH, gs_h = (dymax == dymin) ? a.SH : 1;  // one row offset only: keep just the rows that are read
