@@ -10,7 +10,7 @@ namespace bt {
 // Tile geometry of the specialised kernel (bt_fused_fast.h): t_NI images x t_R output rows x t_Wt output columns per tile,
 // chosen so the x patch of 4 channels (worst case: every tap active) fits the LDS x buffer. Returns false when this launch
 // has to run the general kernel.
-template <int BM, bool LINEAR>
+template <int BM, bool LINEAR, bool FLIP = false>
 static bool fast_geometry(FwdArgs& a) {
   static const bool forced_off = getenv("BT_FORCE_GENERIC") != nullptr;  // A/B hook for tests and benchmarks
   if (forced_off || !a.mu_pk || (((uintptr_t)a.mu_pk | (uintptr_t)a.sig_pk) & 15u) || a.T > kMaxTaps / 2 || a.w_elems >= (1ll << 29) ||
@@ -40,6 +40,21 @@ static bool fast_geometry(FwdArgs& a) {
     if (!fits(NI, R, Wt)) return false;
   }
   const bool grid = a.pixel_major || (!LINEAR && a.HoWo > 1);
+  // Row-chunk staging of the x patch (16-byte pieces of input rows copied straight into LDS): needs 16-byte aligned rows
+  // and the slightly wider patch to fit with the same tile. Flipout stages x through registers (it multiplies by the signs).
+  a.x_rows = 0;
+  static const bool no_rows = getenv("BT_NO_XROWS") != nullptr;  // A/B hook
+  if (!no_rows && !LINEAR && !FLIP && !a.pixel_major && a.HoWo > 1 && (a.W & 3) == 0 && (((uintptr_t)a.x) & 15u) == 0 && (a.x_sample_stride & 3) == 0) {
+    const long long PHt = (long long)(R - 1) * (dys ? a.SH : 1) + dys + 1;
+    int xa, n;
+    if (Wt == a.Wo) {
+      n = row_chunks(-a.PW, -a.PW + (Wt - 1) * a.SW + dxs, a.W, &xa);  // the tile spans the row: exact (all taps active is the worst case)
+    } else {
+      n = (((Wt - 1) * a.SW + dxs + 1 + 3) >> 2) + 1;                    // column segments: any alignment of the first column
+    }
+    const long long PCH = NI * PHt * 4 * n + 4;
+    if (4 * PCH <= XW && PCH < 65536) a.x_rows = 1;
+  }
   a.t_NI = NI, a.t_R = R, a.t_Wt = Wt;
   a.n_bt = (a.B + NI - 1) / NI;
   a.n_rt = grid ? (a.Ho + R - 1) / R : 1;
@@ -66,7 +81,7 @@ static int launch_cfg(FwdArgs& a, hipStream_t stream) {
   static_assert(lds <= 160 * 1024, "LDS budget of one CU");
   a.n_tiles = (a.Cog + BN - 1) / BN;
   bool fast = false;
-  if constexpr (!INJ) fast = fast_geometry<BM, LINEAR>(a);  // injected draws are the parity/debug mode: always the general kernel
+  if constexpr (!INJ) fast = fast_geometry<BM, LINEAR, FLIP>(a);  // injected draws are the parity/debug mode: always the general kernel
   if (!fast) {  // general kernel: BM consecutive (b, ho, wo), or pixel-major
     if (a.pixel_major) {
       a.mt_per_pixel = (a.B + BM - 1) / BM;

@@ -13,6 +13,14 @@
 
 namespace bt {
 
+// buffer_load_dwordx4 ... lds: lane l copies 16 bytes from (resource base + voffset[l] + soffset) to lds_wave_base + 16 * l;
+// an out-of-range lane writes zeros, a masked lane writes nothing (tools/ubench/lds_dma.hip). Tracked by vmcnt.
+__device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t& r, float* lds_wave_base, int voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the builtin exists in the device pass only
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset, 0, 0);
+#endif
+}
+
 template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, bool INJ>
 __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
   constexpr int CWM = 4 / CWN;
@@ -121,9 +129,17 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
   const int dymin = __builtin_amdgcn_readfirstlane(misc[2]), dymax = __builtin_amdgcn_readfirstlane(misc[3]);
   const int dxmin = __builtin_amdgcn_readfirstlane(misc[4]), dxmax = __builtin_amdgcn_readfirstlane(misc[5]);
   const int ps_h = (dymax == dymin) ? 1 : a.SH, gs_h = (dymax == dymin) ? a.SH : 1;
-  const int ps_w = (dxmax == dxmin) ? 1 : a.SW, gs_w = (dxmax == dxmin) ? a.SW : 1;
-  const int PHt = (t_R - 1) * ps_h + (dymax - dymin) + 1, PWt = (t_Wt - 1) * ps_w + (dxmax - dxmin) + 1;
-  const int PIMG = PHt * PWt, PCH = t_NI * PIMG;
+  // Row-chunk mode (host flag): patch rows are whole 16-byte chunks of the input rows, copied global -> LDS without passing
+  // through registers; the patch keeps every input column (ps_w = stride) and starts at a multiple of 4.
+  constexpr bool kRows = !LINEAR && !FLIP;
+  const bool xrows = kRows && a.x_rows != 0;
+  const int x_lo = w0 * a.SW - a.PW + dxmin;  // input column of the first tap of the first output column
+  int xa = x_lo, nchk = 0;
+  if (xrows) nchk = row_chunks(x_lo, x_lo + (t_Wt - 1) * a.SW + (dxmax - dxmin), a.W, &xa);
+  const int xshift = x_lo - xa;
+  const int ps_w = (xrows || dxmax != dxmin) ? a.SW : 1, gs_w = (xrows || dxmax != dxmin) ? 1 : a.SW;
+  const int PHt = (t_R - 1) * ps_h + (dymax - dymin) + 1, PWt = xrows ? 4 * nchk : (t_Wt - 1) * ps_w + (dxmax - dxmin) + 1;
+  const int PIMG = PHt * PWt, PCH = t_NI * PIMG + (xrows ? 4 : 0);
   if (!LINEAR)
     while (CC > 4 && CC * PCH > X_WORDS) CC >>= 1;  // the host guaranteed 4 * PCH <= X_WORDS
   const int lcc = 31 - __clz(CC);
@@ -137,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
       int off = t * XS;
       if (!LINEAR) {
         const int4 e = taptab[a0 + (t >> lcc)];
-        off = (t & (CC - 1)) * PCH + (e.y - dymin) * PWt + (e.z - dxmin);
+        off = (t & (CC - 1)) * PCH + (e.y - dymin) * PWt + (e.z - dxmin) + xshift;
       }
       rowtab[slot * 40 + t] = off;
     }
@@ -197,11 +213,29 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
     const int wave_u0 = __builtin_amdgcn_readfirstlane(ptid & ~63);
     // x patch: this thread owns plane positions ptid + 256*i (all channels of a stage)
     constexpr int PPOS = (X_WORDS / 4 + kProducers - 1) / kProducers;
+    constexpr int QPOS = (X_WORDS / 16 + kProducers - 1) / kProducers;  // row-chunk mode: 16-byte chunks of one channel plane
     int p_off[PPOS];
-    if (!LINEAR) {
+    int q_off[kRows ? QPOS : 1];
+    const int y_lo = r0 * a.SH - a.PH + dymin;  // input row of the patch origin
+    const int NCHK = t_NI * PHt * nchk + 1;     // chunks per channel plane, the closing spare included
+    if (xrows) {
+      const int per_img = PHt * nchk;
+      const uint32_t inv_img = (uint32_t)((0x100000000ull + (unsigned)per_img - 1) / (unsigned)per_img);
+      const uint32_t inv_n = (uint32_t)((0x100000000ull + (unsigned)nchk - 1) / (unsigned)nchk);
+#pragma unroll
+      for (int i = 0; i < (kRows ? QPOS : 1); ++i) {
+        const int q = ptid + kProducers * i;
+        const int qq = q < NCHK - 1 ? q : 0;
+        const int img = per_img == 1 ? qq : (int)__umulhi((uint32_t)qq, inv_img);
+        const int rem = qq - img * per_img;
+        const int yy = nchk == 1 ? rem : (int)__umulhi((uint32_t)rem, inv_n);
+        const int b = b0 + img, y = y_lo + yy * gs_h, x = xa + 4 * (rem - yy * nchk);
+        const bool ok = q < NCHK - 1 && b < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        q_off[i] = ok ? 4 * ((b * a.Ci + g * Cig) * a.HW + y * a.W + x) : (int)kOOB;  // halo chunks read (and write) zeros
+      }
+    } else if (!LINEAR) {
       const uint32_t inv_pimg = (uint32_t)((0x100000000ull + (unsigned)PIMG - 1) / (unsigned)PIMG);
       const uint32_t inv_pw = (uint32_t)((0x100000000ull + (unsigned)PWt - 1) / (unsigned)PWt);
-      const int y_lo = r0 * a.SH - a.PH + dymin, x_lo = w0 * a.SW - a.PW + dxmin;  // input coordinates of the patch origin
 #pragma unroll
       for (int i = 0; i < PPOS; ++i) {
         const int pos = ptid + kProducers * i;
@@ -272,6 +306,23 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
             for (int j = 0; j < 4; ++j) xo[4 * p + j] = off + j;
           }
         }
+      } else if (xrows) {
+        if constexpr (kRows) {
+          if (ach == 0) {  // 16-byte row chunks, global -> LDS directly: lane l of a wave fills chunk (wave's first chunk + l)
+#pragma unroll
+            for (int c = 0; c < CCs; ++c) {
+              const bool chan = c0 + c < Cig;  // uniform; a padded channel's plane is filled with zeros
+              const int soff = chan ? 4 * (c0 + c) * a.HW : 0;
+#pragma unroll
+              for (int i = 0; i < QPOS; ++i) {
+                if (wave_u0 + kProducers * i < NCHK) {  // wave-uniform
+                  if (ptid + kProducers * i < NCHK)
+                    lds_dma16(r_x, Xt0 + c * PCH + 4 * (wave_u0 + kProducers * i), chan ? q_off[i] : (int)kOOB, soff);
+                }
+              }
+            }
+          }
+        }
       } else if (ach == 0) {  // later tap chunks reuse the staged patch
         const int c0HWb = 4 * c0 * a.HW, HWb = 4 * a.HW;
 #pragma unroll
@@ -325,7 +376,7 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
             }
           }
         }
-      } else if (ach == 0) {
+      } else if (ach == 0 && !xrows) {
 #pragma unroll
         for (int i = 0; i < PC; ++i) {
           const int pos = ptid + kProducers * i;
@@ -385,6 +436,9 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
       osh[ptid] = cv ? sh : 0.f;
     }
     __syncthreads();
+    if (TRANS && a.out_vec4) {  // the consumers pass the output tile through LDS: keep them company at their barriers
+      for (int i = 0; i < 2 * TN - 1; ++i) __syncthreads();
+    }
   } else {
     // =================================================== CONSUMERS ===========================================================
     if (kl_block) {
@@ -537,37 +591,68 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
     const float* const res_s = a.ep_res ? a.ep_res + (long long)s * a.ep_res_stride : nullptr;
     const bool relu = a.ep_relu != 0;
     if (TRANS && a.out_vec4) {
-      // spatial NCHW output through the D[m][co] orientation: a lane owns ONE output channel (bias / scale / shift are lane
-      // constants) and registers 4q..4q+3 are 4 consecutive output positions -> one 16-byte store (and residual load) per 4
-      // values. The host guarantees Wo % 4 == 0 (tile widths are multiples of 4) and 16-byte aligned tensors: a quad stays in one row.
+      // Spatial NCHW output. The accumulators come out of the D[m][co] orientation with a lane owning ONE output channel
+      // (bias / scale / shift are lane constants) and registers 4q..4q+3 holding 4 consecutive output positions; stored
+      // from there, the 64 lanes of a wave would hit 64 different 128-byte lines with 16 bytes each. So the tile goes
+      // through LDS, 32 * CWN channels at a time: [channel][BM positions], read back with consecutive lanes on
+      // consecutive 16-byte pieces of one channel -> whole lines per store (and per residual load). The host guarantees
+      // Wo % 4 == 0, tile widths that are multiples of 4 and 16-byte aligned tensors: a quad never leaves its row.
+      constexpr int SROW = BM + 4, SROWS = 32 * CWN;
+      static_assert(4 * BN + SROWS * SROW <= 2 * BUF_WORDS, "output staging fits the operand buffers");
+      float* const stage = smem + 4 * BN;  // past the bias / scale / shift vectors
+      float bsv[TN], b1v[TN], scv[TN], shv[TN];
 #pragma unroll
-      for (int j = 0; j < TM; ++j) {
+      for (int i = 0; i < TN; ++i) {
+        const int co_l = wn * WTN + i * 32 + li;
+        bsv[i] = bias0[co_l], scv[i] = osc[co_l], shv[i] = osh[co_l];
+        b1v[i] = FLIP ? bias1[co_l] : 0.f;
+      }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          int bq, hq, wq;
-          const bool mok = col_decode(wm * WTM + j * 32 + 8 * q + 4 * lh, bq, hq, wq);  // t_Wt % 4 == 0: the quad stays in one row
+      for (int i = 0; i < TN; ++i) {
+        if (i > 0) __syncthreads();  // the previous pass has been read out
+        float* const srow = stage + (wn * 32 + li) * SROW + wm * WTM + 4 * lh;
 #pragma unroll
-          for (int i = 0; i < TN; ++i) {
-            const int co_l = wn * WTN + i * 32 + li;
-            const bool ok = mok && n0 + co_l < a.Cog;
-            const uint32_t oidx = ok ? (uint32_t)(((bq * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hq) * a.Wo + wq) : 0u;
-            const float bs = bias0[co_l], sc = osc[co_l], sh = osh[co_l];
-            float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (res_s) r4 = *reinterpret_cast<const float4*>(res_s + oidx);
+        for (int j = 0; j < TM; ++j) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
             float v[4];
+            uint32_t oidx = 0;
+            if constexpr (FLIP) {
+              int bq, hq, wq;
+              const bool mok = col_decode(wm * WTM + j * 32 + 8 * q + 4 * lh, bq, hq, wq);
+              const int co_l = wn * WTN + i * 32 + li;
+              oidx = (mok && n0 + co_l < a.Cog) ? (uint32_t)(((bq * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hq) * a.Wo + wq) : 0u;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              v[e] = __fadd_rn(acc[0][i][j][4 * q + e], bs);
+              v[e] = __fadd_rn(acc[0][i][j][4 * q + e], bsv[i]);
               if constexpr (FLIP) {
                 const float so = INJ ? sout_s[oidx + e] : hash_sign(skey_out, oidx + e);
-                v[e] = __fadd_rn(v[e], __fmul_rn(__fadd_rn(acc[NW - 1][i][j][4 * q + e], bias1[co_l]), so));
+                v[e] = __fadd_rn(v[e], __fmul_rn(__fadd_rn(acc[NW - 1][i][j][4 * q + e], b1v[i]), so));
               }
-              v[e] = __fadd_rn(__fmul_rn(v[e], sc), sh);
+              v[e] = __fadd_rn(__fmul_rn(v[e], scv[i]), shv[i]);
             }
-            v[0] = __fadd_rn(v[0], r4.x), v[1] = __fadd_rn(v[1], r4.y), v[2] = __fadd_rn(v[2], r4.z), v[3] = __fadd_rn(v[3], r4.w);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (relu && v[e] < 0.f) ? 0.f : v[e];
-            if (ok) *reinterpret_cast<float4*>(out_s + oidx) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(srow + j * 32 + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+        __syncthreads();
+        // read-out: quad c = (row, 4 positions); consecutive threads take consecutive quads of a row
+        constexpr int QROW = BM / 4, NQ = SROWS * QROW;
+#pragma unroll 4
+        for (int c = tid; c < NQ; c += 256) {
+          const int row = c / QROW, m4 = c - row * QROW;
+          int bq, hq, wq;
+          const bool mok = col_decode(4 * m4, bq, hq, wq);
+          const int co_l = (row >> 5) * WTN + i * 32 + (row & 31);
+          if (mok && n0 + co_l < a.Cog) {
+            const uint32_t oidx = (uint32_t)(((bq * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hq) * a.Wo + wq);
+            float4 v = *reinterpret_cast<const float4*>(stage + row * SROW + 4 * m4);
+            if (res_s) {
+              const float4 r4 = *reinterpret_cast<const float4*>(res_s + oidx);
+              v.x = __fadd_rn(v.x, r4.x), v.y = __fadd_rn(v.y, r4.y), v.z = __fadd_rn(v.z, r4.z), v.w = __fadd_rn(v.w, r4.w);
+            }
+            if (relu) v.x = v.x < 0.f ? 0.f : v.x, v.y = v.y < 0.f ? 0.f : v.y, v.z = v.z < 0.f ? 0.f : v.z, v.w = v.w < 0.f ? 0.f : v.w;
+            *reinterpret_cast<float4*>(out_s + oidx) = v;
           }
         }
       }

@@ -51,6 +51,7 @@ struct FwdArgs {
   int n_tiles, m_tiles, total_blocks;
   int t_NI, t_R, t_Wt, n_bt, n_rt, n_ct;  // fast flavour: tile = t_NI images x t_R rows x t_Wt cols; tile grid per (n-tile, sample)
   int patch_ok;                   // host: tiles are whole images (or pixel-major), so the x operand can be staged as a patch
+  int x_rows;                     // host (fast flavour): stage the x patch as 16-byte row chunks written straight to LDS
   int pixel_major, mt_per_pixel;  // m-tile = (one output pixel, BM images) instead of BM consecutive (b, ho, wo)
   int w_vec, x_vec;               // float4 paths allowed (taps == 1, K % 4 == 0, 16-B aligned bases)
   int do_kl, kl_slices;
@@ -69,6 +70,18 @@ struct FwdArgs {
 __device__ __forceinline__ int xcd_remap(int orig, int n) {
   const int q = n >> 3, r = n & 7, xcd = orig & 7, i = orig >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+// Row-chunk patch (fast flavour, W % 4 == 0): a patch row holds the 16-byte chunks [xa, xa + 4 * n) of an input row, xa = the
+// patch's first input column rounded down to a multiple of 4, so every chunk is entirely inside or entirely outside the
+// row. When the first chunk and the last are both outside, the last is dropped: those cells alias the next row's first
+// chunk, which is zero as well (one spare chunk closes the plane).
+__host__ __device__ inline int row_chunks(int x_lo, int x_hi, int W, int* xa_out) {
+  const int xa = x_lo & ~3;
+  int n = ((x_hi - xa) >> 2) + 1;
+  if (n > 1 && xa + 4 * (n - 1) >= W && xa + 4 <= 0) --n;
+  *xa_out = xa;
+  return n;
 }
 
 // Words of one LDS x buffer. Tiles up to 256 columns hold kBK im2col rows; the 512-wide tile (fast flavour only) stages x
