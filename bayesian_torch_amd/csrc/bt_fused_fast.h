@@ -184,6 +184,9 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
   const bool kl_block = a.do_kl && (int)blockIdx.x < a.kl_slices;
 
   if (producer) {
+    // Producer instructions win issue arbitration over the consumer wave of the same SIMD: their VALU work slots in
+    // between MFMAs instead of waiting for the consumer to stall.
+    if (!a.dbg || a.dbg[200] == 0) __builtin_amdgcn_s_setprio(3);
     // =================================================== PRODUCERS ===========================================================
     // ---- per-thread state, decoded once ----
     constexpr int UMAX = (BN * 9 + kProducers - 1) / kProducers;
@@ -342,8 +345,8 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
       if constexpr (!INJ) {
 #pragma unroll
         for (int i = 0; i < UMAX; ++i)
-          if ((i == 0 || wave_u0 + kProducers * i < nunits) && c0 < c_lim[i] && u_ai[i] < na_s)
-            philox_normal4(key_w, sample, (e_off[i] + tap_e[i] + (uint32_t)c0) >> 2, ep[i]);
+          if (i == 0 || wave_u0 + kProducers * i < nunits)  // wave-uniform only: masked lanes cost nothing, and without per-lane
+            philox_normal4(key_w, sample, (e_off[i] + tap_e[i] + (uint32_t)c0) >> 2, ep[i]);  // branches the units' chains interleave
       }
       if (pst) a.dbg[252] = __builtin_amdgcn_s_memtime();
       // ---- sampled weights -> LDS ----
@@ -393,18 +396,19 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
     };
 
     const bool stamp = a.dbg && blockIdx.x == 0 && tid == 256;
-    for (int st = 0; st <= NS; ++st) {  // NS + 1 barriers, like the consumer arm
-      if (stamp && st < 60) a.dbg[128 + 2 * st] = __builtin_amdgcn_s_memtime();
-      if (st < NS) {
-        switch (lcc) {
-          case 2: produce(std::integral_constant<int, 2>{}, st); break;
-          case 3: produce(std::integral_constant<int, 3>{}, st); break;
-          case 4: produce(std::integral_constant<int, 4>{}, st); break;
-          default: produce(std::integral_constant<int, 5>{}, st); break;
-        }
+    auto run_stages = [&](auto LCCc) {  // one loop per channel-chunk width: each carries only its own loop invariants
+      for (int st = 0; st <= NS; ++st) {  // NS + 1 barriers, like the consumer arm
+        if (stamp && st < 60) a.dbg[128 + 2 * st] = __builtin_amdgcn_s_memtime();
+        if (st < NS) produce(LCCc, st);
+        if (stamp && st < 60) a.dbg[128 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
+        __syncthreads();
       }
-      if (stamp && st < 60) a.dbg[128 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
-      __syncthreads();
+    };
+    switch (lcc) {
+      case 2: run_stages(std::integral_constant<int, 2>{}); break;
+      case 3: run_stages(std::integral_constant<int, 3>{}); break;
+      case 4: run_stages(std::integral_constant<int, 4>{}); break;
+      default: run_stages(std::integral_constant<int, 5>{}); break;
     }
     // bias draw + output-stage constants of this workgroup's channels
     if (ptid < BN) {

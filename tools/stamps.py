@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bayesian_torch_amd import _lib, functional as F
 sys.argv = [sys.argv[0]] + sys.argv[1:]
 import argparse
-ap = argparse.ArgumentParser(); ap.add_argument("--shape", default="layer1"); ap.add_argument("--S", type=int, default=32); ap.add_argument("--B", type=int, default=128); ap.add_argument("--sigma", action="store_true")
+ap = argparse.ArgumentParser(); ap.add_argument("--shape", default="layer1"); ap.add_argument("--S", type=int, default=32); ap.add_argument("--B", type=int, default=128); ap.add_argument("--sigma", action="store_true"); ap.add_argument("--noprio", action="store_true")
 a = ap.parse_args()
 SH = {"conv1": (3, 64, 7, 2, 3, 32), "layer1": (64, 64, 3, 1, 1, 8), "layer2": (128, 128, 3, 1, 1, 4), "layer3": (256, 256, 3, 1, 1, 2), "layer4": (512, 512, 3, 1, 1, 1)}
 Ci, Co, k, st, pd, H = SH[a.shape]
@@ -15,6 +15,7 @@ mu = torch.randn(Co, Ci, k, k, device=dev) * 0.1; rho = torch.randn(Co, Ci, k, k
 x = torch.randn(a.S * a.B, Ci, H, H, device=dev)
 conv = dict(stride=(st, st), padding=(pd, pd), dilation=(1, 1), groups=1)
 buf = torch.zeros(256, dtype=torch.int64, device=dev)
+if a.noprio: buf[200] = 1
 L = _lib.lib(); L.bt_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]; L.bt_debug_set_stamp_buffer.restype = None
 for i in range(3):
     F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=i, layer_id=3)
