@@ -135,7 +135,7 @@ static int pick_tile(FwdArgs& a, hipStream_t stream) {
   if (a.Cog <= 32) return launch_cfg<32, 128, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
   if constexpr (!FLIP) {  // wide tiles: one accumulator set fits in the consumers' registers (Flipout carries two)
     if constexpr (!LINEAR && !INJ) {  // 512-wide: fast flavour only (x as a patch); halves the weight-synthesis work per MFMA
-      if (Mdom >= 512 && a.Cog <= 64 && tiles_for(a, 64, 512) >= kCUs) {
+      if (Mdom >= 512 && tiles_for(a, 64, 512) >= kCUs) {
         FwdArgs probe = a;
         // only when the wide tile is actually filled (a 256-pixel image whose 2-image patch does not fit would leave half of it dead)
         if (fast_geometry<512, false>(probe) && probe.t_NI * probe.t_R * probe.t_Wt >= 448)
