@@ -34,7 +34,7 @@ class bt_draws(C.Structure):
 
 class bt_epilogue(C.Structure):
     _fields_ = [("scale", _vp), ("shift", _vp), ("residual", _vp), ("residual_sample_stride", C.c_int64), ("relu", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("pool", C.c_int32)]
 
 
 class bt_conv2d_geom(C.Structure):
@@ -80,6 +80,9 @@ def lib():
                     fn.restype, fn.argtypes = res, args
                 _lib = handle
     return _lib
+
+
+ERR_UNSUPPORTED = -2  # BT_ERR_UNSUPPORTED
 
 
 def check(rc):

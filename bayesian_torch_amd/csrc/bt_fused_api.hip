@@ -77,6 +77,13 @@ static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const flo
   a.do_kl = kl_out != nullptr;
   a.seed_lo = (uint32_t)d->rng.seed, a.seed_hi = (uint32_t)(d->rng.seed >> 32);
   if (ep) a.ep_scale = ep->scale, a.ep_shift = ep->shift, a.ep_res = ep->residual, a.ep_res_stride = ep->residual_sample_stride, a.ep_relu = ep->relu;
+  if (ep && ep->pool != BT_POOL_NONE) {
+    if (ep->pool != BT_POOL_MAX_3x3_S2_P1) return bad("unknown epilogue pool mode");
+    if (linear) return bad("the fused max-pool belongs to the conv2d entry points");
+    if (ep->residual) return bad("the fused max-pool takes no residual");
+    a.ep_pool = 1, a.ep_Hp = (Ho - 1) / 2 + 1, a.ep_Wp = (Wo - 1) / 2 + 1;
+    a.out_elems = (long long)g.B * g.Co * a.ep_Hp * a.ep_Wp;
+  }
   a.out_vec4 = (!linear && !a.pixel_major && a.HoWo > 1 && (a.Wo & 3) == 0 && al16(out) && (!a.ep_res || (al16(a.ep_res) && (a.ep_res_stride & 3) == 0)) &&
                 (!d->sign_out || al16(d->sign_out))) ? 1 : 0;
   a.dbg = g_dbg;
@@ -86,6 +93,7 @@ static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const flo
   const bool all_inj = inj && (!p->mu_b || d->eps_b) && (!flip || (d->sign_in && d->sign_out));
   const bool none_inj = !d->eps_w && !d->eps_b && !d->sign_in && !d->sign_out;
   if (!all_inj && !none_inj) return bad("inject all draws of the layer (eps_w, eps_b when biased, both sign tensors for Flipout) or none");
+  if (inj && a.ep_pool) return set_error(BT_ERR_UNSUPPORTED, "fused max-pool: not available with injected draws");
   if (inj) return flip ? launch_flipout_inj(linear, a, (hipStream_t)stream) : launch_reparam_inj(linear, a, (hipStream_t)stream);
   return flip ? launch_flipout(linear, a, (hipStream_t)stream) : launch_reparam(linear, a, (hipStream_t)stream);
 }

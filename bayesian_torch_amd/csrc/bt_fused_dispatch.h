@@ -82,6 +82,8 @@ static int launch_cfg(FwdArgs& a, hipStream_t stream) {
   a.n_tiles = (a.Cog + BN - 1) / BN;
   bool fast = false;
   if constexpr (!INJ) fast = fast_geometry<BM, LINEAR, FLIP>(a);  // injected draws are the parity/debug mode: always the general kernel
+  if (a.ep_pool && !(fast && TRANS && a.out_vec4 && !a.pixel_major && a.t_R == a.Ho && a.t_Wt == a.Wo))
+    return set_error(BT_ERR_UNSUPPORTED, "fused max-pool: this launch's tiles do not hold whole output images");
   if (!fast) {  // general kernel: BM consecutive (b, ho, wo), or pixel-major
     if (a.pixel_major) {
       a.mt_per_pixel = (a.B + BM - 1) / BM;
@@ -124,7 +126,27 @@ static inline long long tiles_for(const FwdArgs& a, int BN, int BM) {
 }
 
 template <bool FLIP, bool LINEAR, bool TRANS, bool INJ>
+static int pick_tile_by_size(FwdArgs& a, hipStream_t stream);
+
+template <bool FLIP, bool LINEAR, bool TRANS, bool INJ>
 static int pick_tile(FwdArgs& a, hipStream_t stream) {
+  const int rc = pick_tile_by_size<FLIP, LINEAR, TRANS, INJ>(a, stream);
+  if constexpr (!LINEAR && !INJ) {
+    // The fused max-pool needs tiles of whole images. When the size-driven choice has none (small batches pick narrow
+    // tiles), take the narrowest tile that holds an image; launch_cfg launches nothing when it declines.
+    if (rc == BT_ERR_UNSUPPORTED && a.ep_pool) {
+      if (a.HoWo <= 128) return launch_cfg<64, 128, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);
+      if constexpr (!FLIP) {
+        if (a.HoWo <= 256) return launch_cfg<64, 256, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
+        if (a.HoWo <= 512) return launch_cfg<64, 512, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
+      }
+    }
+  }
+  return rc;
+}
+
+template <bool FLIP, bool LINEAR, bool TRANS, bool INJ>
+static int pick_tile_by_size(FwdArgs& a, hipStream_t stream) {
   // Workgroup tile = BN output channels x BM output positions; 4 consumer waves of (BN/CWN) x (BM/CWM) each.
   // Wide BM amortises one weight draw over more MFMA work (the producers' VALU budget); a launch should still
   // offer >= 256 workgroups (one per CU), so tiles shrink when the grid would not fill the chip.

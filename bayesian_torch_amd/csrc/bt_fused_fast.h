@@ -640,6 +640,38 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
           }
         }
         __syncthreads();
+        if (a.ep_pool) {
+          // fused MaxPool2d(3, 2, 1) of whole staged images (tile column = (img * Ho + ho) * Wo + wo); NaN wins like torch's
+          const int Hp = a.ep_Hp, Wp = a.ep_Wp, PP = Hp * Wp, per_row = t_NI * PP;
+          const uint32_t inv_row = (uint32_t)((0x100000000ull + (unsigned)per_row - 1) / (unsigned)per_row);
+          const uint32_t inv_pp = (uint32_t)((0x100000000ull + (unsigned)PP - 1) / (unsigned)PP);
+          const uint32_t inv_wp = (uint32_t)((0x100000000ull + (unsigned)Wp - 1) / (unsigned)Wp);
+          for (int c = tid; c < SROWS * per_row; c += 256) {  // < 2^16: the magic divisions are exact
+            const int row = per_row == 1 ? c : (int)__umulhi((uint32_t)c, inv_row), rem = c - row * per_row;
+            const int img = PP == 1 ? rem : (int)__umulhi((uint32_t)rem, inv_pp), pp = rem - img * PP;
+            const int py = Wp == 1 ? pp : (int)__umulhi((uint32_t)pp, inv_wp), px = pp - py * Wp;
+            const int co_l = (row >> 5) * WTN + i * 32 + (row & 31), b = b0 + img;
+            if (b < a.B && n0 + co_l < a.Cog) {
+              const float* const plane = stage + row * SROW + img * RW;
+              float m = -INFINITY;
+#pragma unroll
+              for (int dy = 0; dy < 3; ++dy) {
+                const int y = 2 * py - 1 + dy;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                  const int x = 2 * px - 1 + dx;
+                  if ((unsigned)y < (unsigned)a.Ho && (unsigned)x < (unsigned)a.Wo) {
+                    const float v = plane[y * a.Wo + x];
+                    m = (v > m || v != v) ? v : m;
+                  }
+                }
+              }
+              if (relu) m = m < 0.f ? 0.f : m;  // max and ReLU commute
+              out_s[((b * a.Co + g * a.Cog + n0 + co_l) * Hp + py) * Wp + px] = m;
+            }
+          }
+          continue;
+        }
         // read-out: quad c = (row, 4 positions); consecutive threads take consecutive quads of a row
         constexpr int QROW = BM / 4, NQ = SROWS * QROW;
 #pragma unroll 4

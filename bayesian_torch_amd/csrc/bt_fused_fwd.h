@@ -60,6 +60,7 @@ struct FwdArgs {
   const float *ep_scale, *ep_shift, *ep_res;  // fused output stage (bt_epilogue)
   long long ep_res_stride;
   int ep_relu;
+  int ep_pool, ep_Hp, ep_Wp;  // fused 3x3 / stride 2 / pad 1 max-pool of the output stage (fast flavour, whole-image tiles)
   int out_vec4;  // spatial output stored as float4 along the pixel index (TRANS orientation; Ho*Wo % 4 == 0, aligned tensors)
   unsigned long long* dbg;  // diagnostic stamps (bt_debug_set_stamp_buffer); null in normal operation
 };

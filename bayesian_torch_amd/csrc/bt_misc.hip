@@ -146,10 +146,42 @@ extern "C" int bt_rng_philox_raw(uint64_t seed, const uint32_t ctr[4], uint32_t 
   return BT_OK;
 }
 
+// C <= 64 (the usual classifier head): one WAVE per batch row, lane c owns class c; no barriers, samples in fixed order.
+__global__ __launch_bounds__(256) void mc_epilogue_small_kernel(int S, int B, int C, const float* __restrict__ logits, float* __restrict__ packed) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const bool on = lane < C;
+  float psum = 0.f, lsum = 0.f, ent_total = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float x = on ? logits[((long long)s * B + b) * C + lane] : -INFINITY;
+    float mx = x;
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float z = x - mx;
+    const float e = on ? expf(z) : 0.f;
+    float den = e;
+    for (int o = 32; o > 0; o >>= 1) den += __shfl_xor(den, o, 64);
+    const float lden = logf(den);
+    const float p = e / den;
+    psum += p;
+    lsum += on ? x : 0.f;
+    float ent = (on && p > 0.f) ? -p * (z - lden) : 0.f;
+    for (int o = 32; o > 0; o >>= 1) ent += __shfl_xor(ent, o, 64);
+    ent_total += ent;
+  }
+  if (on) {
+    packed[(long long)b * C + lane] = psum;
+    packed[(long long)B * C + B + (long long)b * C + lane] = lsum;
+  }
+  if (lane == 0) packed[(long long)B * C + b] = ent_total;
+}
+
 extern "C" int bt_mc_epilogue(int32_t S, int32_t B, int32_t C, const float* logits, float* packed, bt_stream_t stream) {
   using namespace bt;
   if (S <= 0 || B <= 0 || C <= 0 || !logits || !packed) return set_error(BT_ERR_BAD_ARG, "bt_mc_epilogue: bad argument");
-  hipLaunchKernelGGL(mc_epilogue_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, S, B, C, logits, packed);
+  if (C <= 64)
+    hipLaunchKernelGGL(mc_epilogue_small_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, B, C, logits, packed);
+  else
+    hipLaunchKernelGGL(mc_epilogue_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, S, B, C, logits, packed);
   return check_launch("bt_mc_epilogue");
 }
 

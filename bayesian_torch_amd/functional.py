@@ -11,10 +11,22 @@ def conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, dh, dw):
     return (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1, (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
 
 
-def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=None, S=1, shared_x=True,
-                  priors=None, eps_w=None, eps_b=None, sign_in=None, sign_out=None,
-                  seed=0, call=0, layer_id=0, sample0=0, call_base=None, want_kl=False, workspace_owner="functional",
-                  post_scale=None, post_shift=None, residual=None, relu=False, packed=None):
+def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, pool=False, **kw):
+    """See _fused_forward.  pool=True appends MaxPool2d(3, 2, 1) to the output stage (the ResNet stem): fused into the
+    launch when its tiles hold whole output images, else run as a separate pooling pass on the launch's output."""
+    if not pool:
+        return _fused_forward(x, mu_w, rho_w, mu_b, rho_b, pool=False, **kw)
+    r = _fused_forward(x, mu_w, rho_w, mu_b, rho_b, pool=True, **kw)
+    if r is None:  # BT_ERR_UNSUPPORTED: nothing was launched
+        out, kl = _fused_forward(x, mu_w, rho_w, mu_b, rho_b, pool=False, **kw)
+        return torch.nn.functional.max_pool2d(out, 3, 2, 1), kl
+    return r
+
+
+def _fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=None, S=1, shared_x=True,
+                   priors=None, eps_w=None, eps_b=None, sign_in=None, sign_out=None,
+                   seed=0, call=0, layer_id=0, sample0=0, call_base=None, want_kl=False, workspace_owner="functional",
+                   post_scale=None, post_shift=None, residual=None, relu=False, packed=None, pool=False):
     """x: [B, In] (conv=None) or [B, Ci, H, W]; when ``shared_x`` is False x holds S stacked batches
     ([S*B, ...]).  conv: dict(stride=(sh,sw), padding=(ph,pw), dilation=(dh,dw), groups=g) for Conv2d.
     priors: (prior_mu_w, prior_sigma_w, prior_mu_b, prior_sigma_b) -- required when want_kl.
@@ -53,6 +65,10 @@ def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=Non
         tail = (Co, Ho, Wo)
         geom = _lib.bt_conv2d_geom(B, Ci, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups)
     x_elems = x.numel() // (1 if shared_x else S)
+    if pool:
+        if conv is None or residual is not None:
+            raise RuntimeError("pool=True needs a Conv2d launch without residual")
+        tail = (Co, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1)
     out = torch.empty((S * B,) + tail, dtype=torch.float32, device=dev)
     kl = ws = None
     pr = [None] * 4
@@ -67,7 +83,7 @@ def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=Non
     R = _lib.bt_rng(int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(call_base), int(call) & 0xFFFFFFFF, int(layer_id), int(sample0), 0)
     D = _lib.bt_draws(_lib.ptr(tens["eps_w"]), _lib.ptr(tens["eps_b"]), _lib.ptr(tens["sign_in"]), _lib.ptr(tens["sign_out"]), R)
     E = None
-    if tens["post_scale"] is not None or tens["residual"] is not None or relu:
+    if tens["post_scale"] is not None or tens["residual"] is not None or relu or pool:
         res, rstride = tens["residual"], 0
         if res is not None:
             if res.numel() == out.numel():
@@ -76,7 +92,7 @@ def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=Non
                 raise RuntimeError(f"residual has {res.numel()} elements, out has {out.numel()} (S={S})")
         if tens["post_scale"] is not None and (tens["post_scale"].numel() != Co or tens["post_shift"] is None or tens["post_shift"].numel() != Co):
             raise RuntimeError("post_scale / post_shift must both have Co elements")
-        E = C.byref(_lib.bt_epilogue(_lib.ptr(tens["post_scale"]), _lib.ptr(tens["post_shift"]), _lib.ptr(res), rstride, 1 if relu else 0, 0))
+        E = C.byref(_lib.bt_epilogue(_lib.ptr(tens["post_scale"]), _lib.ptr(tens["post_shift"]), _lib.ptr(res), rstride, 1 if relu else 0, 1 if pool else 0))
     tail_args = (x.data_ptr(), 0 if shared_x else x_elems, C.byref(P), C.byref(D), E, out.data_ptr(), _lib.ptr(kl), _lib.ptr(ws),
                  _lib.WORKSPACE_BYTES if want_kl else 0, _lib.stream_ptr())
     L = _lib.lib()
@@ -85,7 +101,10 @@ def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=Non
         _lib.check(fn(B, In, Co, S, *tail_args))
     else:
         fn = L.bt_flipout_conv2d_fwd if flip else L.bt_reparam_conv2d_fwd
-        _lib.check(fn(C.byref(geom), S, *tail_args))
+        rc = fn(C.byref(geom), S, *tail_args)
+        if pool and rc == _lib.ERR_UNSUPPORTED:
+            return None
+        _lib.check(rc)
     return out, kl
 
 

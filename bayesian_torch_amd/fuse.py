@@ -37,6 +37,17 @@ def fold_pair(conv, bn, relu=False):
     conv.post_relu = bool(relu)
 
 
+def fold_maxpool(conv, pool):
+    """Fold a following ``nn.MaxPool2d(3, 2, 1)`` into ``conv``'s output stage (after its folded BN / ReLU, if any)."""
+    if not isinstance(conv, FusedBayesLayer) or conv._kind != "conv":
+        raise TypeError("fold_maxpool needs a Bayesian Conv2d layer of this package")
+    as2 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    if not isinstance(pool, nn.MaxPool2d) or as2(pool.kernel_size) != (3, 3) or as2(pool.stride) != (2, 2) or as2(pool.padding) != (1, 1) \
+            or as2(pool.dilation) != (1, 1) or pool.ceil_mode or pool.return_indices:
+        raise ValueError("only MaxPool2d(kernel_size=3, stride=2, padding=1) folds into the conv")
+    conv.post_pool = True
+
+
 def fold_batchnorm(model):
     """Fold every BatchNorm2d that directly follows a Bayesian Conv2d in its parent's registration order
     (conv1/bn1, conv2/bn2, Sequential(conv, bn) ...) and replace it by nn.Identity.  Returns the number folded.

@@ -91,7 +91,7 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         if getattr(self, "fused", False):
-            x = self.maxpool(self.conv1(x))
+            x = self.conv1(x)  # bn1 / relu / maxpool live in its output stage
         else:
             x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
@@ -142,8 +142,9 @@ def fill_bayes_params(model, seed, mu_std=0.1, rho_mean=-3.0, rho_std=0.1):
 def fuse_inference(model):
     """Fold every BatchNorm / ReLU / residual add of a converted ResNet into the Bayesian convs' output stage
     (bayesian_torch_amd.fuse).  The model must be converted (dnn_to_bnn), on its device and in eval()."""
-    from ..fuse import fold_pair
+    from ..fuse import fold_pair, fold_maxpool
     fold_pair(model.conv1, model.bn1, relu=True)
+    fold_maxpool(model.conv1, model.maxpool)
     for stage in (model.layer1, model.layer2, model.layer3, model.layer4):
         for blk in stage:
             last = 3 if isinstance(blk, _Bottle) else 2

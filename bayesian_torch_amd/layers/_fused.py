@@ -53,6 +53,7 @@ class FusedBayesLayer(BaseVariationalLayer_):
         self._layer_id = rng.new_layer_id()
         self._last = None
         self.post_relu = False    # fused output stage, set by bayesian_torch_amd.fuse (inference-time folding)
+        self.post_pool = False    # ... followed by MaxPool2d(3, 2, 1) (fuse.fold_maxpool: the ResNet stem)
         self.register_buffer("post_scale", None, persistent=False)
         self.register_buffer("post_shift", None, persistent=False)
         self._sigma_cache = None   # ((versions, pointers), (mu_packed, sigma_packed)): a pure function of (mu, rho)
@@ -183,7 +184,7 @@ class FusedBayesLayer(BaseVariationalLayer_):
                                                   or (self.mu_bias is not None and self.mu_bias.requires_grad))
         if needs_grad:
             # training path: same fused forward kernel, gradients through the autograd bridge (autograd.py)
-            if self.post_scale is not None or residual is not None or self.post_relu:
+            if self.post_scale is not None or residual is not None or self.post_relu or self.post_pool:
                 raise RuntimeError("the folded output stage (fuse.py) is inference-only: unfold or run under torch.no_grad()")
             from ..autograd import FusedForward, KLNormal
             opts = dict(flip=self._flip, conv=conv, S=S, shared=shared, seed=seed, call=call, layer_id=self._layer_id, sample0=sample0,
@@ -203,9 +204,13 @@ class FusedBayesLayer(BaseVariationalLayer_):
                                       sign_in=draw.get("sign_in"), sign_out=draw.get("sign_out"), seed=seed, call=call,
                                       layer_id=self._layer_id, sample0=sample0, call_base=call_base, want_kl=want_kl,
                                       workspace_owner=("layer", self._layer_id), post_scale=self.post_scale, post_shift=self.post_shift,
-                                      residual=residual, relu=self.post_relu, packed=self._packed())
+                                      residual=residual, relu=self.post_relu, pool=self.post_pool, packed=self._packed())
+        conv_shape = tuple(out.shape[1:])     # shape of one sample's contraction output (sign_out's shape): before any fused pooling
+        if self.post_pool and conv is not None:
+            conv_shape = (out.shape[1],) + F.conv_out_hw(x.shape[2], x.shape[3], mu_t.shape[2], mu_t.shape[3], *conv["stride"],
+                                                         *conv["padding"], *conv["dilation"])
         self._last = dict(draw=draw or None, rng=(seed, call_base, call, self._layer_id, sample0), S=S,
-                          x_shape=(B,) + tuple(x.shape[1:]), out_shape=(B,) + tuple(out.shape[1:]))
+                          x_shape=(B,) + tuple(x.shape[1:]), out_shape=(B,) + conv_shape)
         if lead is not None:
             out = out.reshape(lead + (self.out_features,))
         if one_d:

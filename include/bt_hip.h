@@ -105,8 +105,15 @@ typedef struct bt_epilogue {
   const float *residual;           /* NULL, or [S][elements of one sample's out] / shared when stride is 0 */
   int64_t residual_sample_stride;  /* elements between samples, or 0 */
   int32_t relu;
-  int32_t reserved;
+  int32_t pool;                    /* BT_POOL_NONE, or BT_POOL_MAX_3x3_S2_P1: conv2d entry points only (see below) */
 } bt_epilogue;
+
+/* Fused max-pool of the output stage's result -- the ResNet stem's conv -> (folded BN) -> ReLU -> MaxPool2d(3, 2, 1) as one
+ * launch: out is [S][B][Co][Hp][Wp] with Hp = (Ho - 1) / 2 + 1, Wp = (Wo - 1) / 2 + 1, NaN-propagating like
+ * torch.nn.functional.max_pool2d. No residual with it. The launch returns BT_ERR_UNSUPPORTED (nothing written) when its tile
+ * does not hold whole output images (large feature maps) or the draws are injected: pool separately then. */
+#define BT_POOL_NONE 0
+#define BT_POOL_MAX_3x3_S2_P1 1
 
 int bt_version(void);
 const char *bt_last_error_string(void);

@@ -292,3 +292,69 @@ def test_fast_kernel_tile_geometries_vs_oracle(Ci, Co, k, st, pd, H, W, B, flip)
         else:
             ref = O.reparam_fwd_ref(x, mu, rho, eps_w[s], mb, rb, eps_b[s], conv)
         assert_close(out[s], ref, RTOL, ATOL, f"sample {s}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Ci,Co,k,st,pd,H,W,B,flip,fusable", [
+    (3, 64, 7, 2, 3, 32, 32, 6, False, True),     # the CIFAR ResNet stem: two 16x16 images per 512-wide tile
+    (3, 24, 7, 2, 3, 32, 32, 5, True, False),     # Flipout has no tile wider than 128 positions: 16x16 images -> separate pass
+    (6, 24, 3, 1, 1, 8, 8, 5, True, True),        # Flipout, 8x8 images, channel count that is not a tile multiple, ragged batch
+    (8, 16, 3, 1, 1, 12, 8, 3, False, True),      # non-square, even sizes
+    (4, 8, 3, 1, 1, 7, 8, 2, False, True),        # odd height: the last pooled row sees a 2-row window
+    (3, 8, 7, 2, 3, 96, 96, 2, False, False),     # 48x48 outputs: row-band tiles -> separate pooling pass
+    (4, 8, 3, 1, 1, 9, 9, 2, False, False),       # Wo % 4 != 0: scalar store path -> separate pooling pass
+])
+def test_fused_maxpool_output_stage(Ci, Co, k, st, pd, H, W, B, flip, fusable):
+    """bt_epilogue.pool: conv -> scale/shift -> ReLU -> MaxPool2d(3, 2, 1) in one launch, against the oracle's forward
+    followed by torch's max_pool2d on the same on-chip draws; geometries the kernel cannot fuse report
+    BT_ERR_UNSUPPORTED at the C ABI and the Python layer pools separately (same result)."""
+    import ctypes as C
+    from oracle import bt_oracle as O
+    from bayesian_torch_amd import functional as F, _lib
+    gen = torch.Generator().manual_seed(Ci * 10 + H)
+    mu = torch.randn(Co, Ci, k, k, generator=gen) * 0.1
+    rho = torch.randn(Co, Ci, k, k, generator=gen) * 0.1 - 3
+    mb, rb = torch.randn(Co, generator=gen) * 0.1, torch.randn(Co, generator=gen) * 0.1 - 3
+    sc, sh = torch.rand(Co, generator=gen) + 0.5, torch.randn(Co, generator=gen) * 0.3
+    x = torch.randn(B, Ci, H, W, generator=gen)
+    conv = dict(stride=(st, st), padding=(pd, pd), dilation=(1, 1), groups=1)
+    S, seed, call, lid, s0 = 2, 5, 1, 4, 0
+    dev = torch.device("cuda")
+    cu = lambda t: t.cuda()
+    packed = F.pack_params(cu(mu), cu(rho))
+    kw = dict(flip=flip, conv=conv, S=S, seed=seed, call=call, layer_id=lid, sample0=s0, packed=packed, post_scale=cu(sc), post_shift=cu(sh), relu=True)
+    direct = F._fused_forward(cu(x), cu(mu), cu(rho), cu(mb), cu(rb), pool=True, **kw)
+    assert (direct is not None) == fusable, "fusability of this geometry changed"
+    out, _ = F.fused_forward(cu(x), cu(mu), cu(rho), cu(mb), cu(rb), pool=True, **kw)
+    full, _ = F.fused_forward(cu(x), cu(mu), cu(rho), cu(mb), cu(rb), **kw)
+    Ho, Wo = full.shape[2], full.shape[3]
+    assert tuple(out.shape) == (S * B, Co, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1)
+    # the fused pool is exactly max_pool2d of the unpooled launch's output (same draws, same arithmetic)
+    assert torch.equal(out, torch.nn.functional.max_pool2d(full, 3, 2, 1))
+    out = out.reshape((S, B) + tuple(out.shape[1:])).cpu()
+    eps_w = F.rng_fill_normal(seed, call, lid, s0, 0, S, mu.shape, dev).cpu()
+    eps_b = F.rng_fill_normal(seed, call, lid, s0, 1, S, (Co,), dev).cpu()
+    for s in range(S):
+        if flip:
+            s_in = F.rng_fill_sign(seed, call, lid, s0, 2, S, x.shape, dev).cpu()
+            s_out = F.rng_fill_sign(seed, call, lid, s0, 3, S, (B, Co, Ho, Wo), dev).cpu()
+            ref = O.flipout_fwd_ref(x, mu, rho, eps_w[s], s_in[s], s_out[s], mb, rb, eps_b[s], conv)
+        else:
+            ref = O.reparam_fwd_ref(x, mu, rho, eps_w[s], mb, rb, eps_b[s], conv)
+        ref = torch.nn.functional.max_pool2d(torch.relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 3, 2, 1)
+        assert_close(out[s], ref, RTOL, ATOL, f"sample {s}")
+
+
+@pytest.mark.gpu
+def test_fused_maxpool_propagates_nan():
+    from bayesian_torch_amd import functional as F
+    mu = torch.zeros(4, 4, 1, 1); mu[range(4), range(4)] = 1.0     # identity 1x1 conv, sigma ~ 0
+    rho = torch.full((4, 4, 1, 1), -40.0)
+    x = torch.randn(2, 4, 8, 8)
+    x[0, 1, 3, 4] = float("nan")
+    conv = dict(stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1)
+    kw = dict(conv=conv, S=1, seed=1, packed=F.pack_params(mu.cuda(), rho.cuda()))
+    out, _ = F.fused_forward(x.cuda(), mu.cuda(), rho.cuda(), pool=True, **kw)
+    full, _ = F.fused_forward(x.cuda(), mu.cuda(), rho.cuda(), **kw)      # NaN in every channel of that pixel (0 * NaN)
+    ref = torch.nn.functional.max_pool2d(full, 3, 2, 1)                   # the device op the unfused path runs: NaN wins
+    assert torch.equal(torch.isnan(out), torch.isnan(ref)) and torch.isnan(ref).any() and not torch.isnan(ref).all()
