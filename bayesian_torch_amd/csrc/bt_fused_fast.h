@@ -640,6 +640,7 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
           }
         }
         __syncthreads();
+        if (stamp) a.dbg[120 + 2 * i] = __builtin_amdgcn_s_memtime();
         if (a.ep_pool) {
           // fused MaxPool2d(3, 2, 1) of whole staged images (tile column = (img * Ho + ho) * Wo + wo); NaN wins like torch's
           const int Hp = a.ep_Hp, Wp = a.ep_Wp, PP = Hp * Wp, per_row = t_NI * PP;
@@ -653,23 +654,27 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
             const int co_l = (row >> 5) * WTN + i * 32 + (row & 31), b = b0 + img;
             if (b < a.B && n0 + co_l < a.Cog) {
               const float* const plane = stage + row * SROW + img * RW;
-              float m = -INFINITY;
+              // all nine loads first (clamped addresses, no branches): one LDS latency per output instead of nine
+              float v[9];
 #pragma unroll
               for (int dy = 0; dy < 3; ++dy) {
                 const int y = 2 * py - 1 + dy;
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                   const int x = 2 * px - 1 + dx;
-                  if ((unsigned)y < (unsigned)a.Ho && (unsigned)x < (unsigned)a.Wo) {
-                    const float v = plane[y * a.Wo + x];
-                    m = (v > m || v != v) ? v : m;
-                  }
+                  const bool in = (unsigned)y < (unsigned)a.Ho && (unsigned)x < (unsigned)a.Wo;
+                  const float t = plane[in ? y * a.Wo + x : 0];
+                  v[dy * 3 + dx] = in ? t : -INFINITY;  // padding never wins (and is not NaN)
                 }
               }
+              float m = -INFINITY;
+#pragma unroll
+              for (int k = 0; k < 9; ++k) m = (v[k] > m || v[k] != v[k]) ? v[k] : m;
               if (relu) m = m < 0.f ? 0.f : m;  // max and ReLU commute
               out_s[((b * a.Co + g * a.Cog + n0 + co_l) * Hp + py) * Wp + px] = m;
             }
           }
+          if (stamp) a.dbg[121 + 2 * i] = __builtin_amdgcn_s_memtime();
           continue;
         }
         // read-out: quad c = (row, 4 positions); consecutive threads take consecutive quads of a row

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bayesian_torch_amd import _lib, functional as F
 sys.argv = [sys.argv[0]] + sys.argv[1:]
 import argparse
-ap = argparse.ArgumentParser(); ap.add_argument("--shape", default="layer1"); ap.add_argument("--S", type=int, default=32); ap.add_argument("--B", type=int, default=128); ap.add_argument("--sigma", action="store_true"); ap.add_argument("--noprio", action="store_true")
+ap = argparse.ArgumentParser(); ap.add_argument("--shape", default="layer1"); ap.add_argument("--S", type=int, default=32); ap.add_argument("--B", type=int, default=128); ap.add_argument("--sigma", action="store_true"); ap.add_argument("--noprio", action="store_true"); ap.add_argument("--pool", action="store_true")
 a = ap.parse_args()
 SH = {"conv1": (3, 64, 7, 2, 3, 32), "layer1": (64, 64, 3, 1, 1, 8), "layer2": (128, 128, 3, 1, 1, 4), "layer3": (256, 256, 3, 1, 1, 2), "layer4": (512, 512, 3, 1, 1, 1)}
 Ci, Co, k, st, pd, H = SH[a.shape]
@@ -20,7 +20,7 @@ L = _lib.lib(); L.bt_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]; L.bt_d
 for i in range(3):
     F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=i, layer_id=3)
 L.bt_debug_set_stamp_buffer(buf.data_ptr())
-F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=9, layer_id=3, packed=(F.pack_params(mu, rho) if a.sigma else None))
+F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=9, layer_id=3, packed=(F.pack_params(mu, rho) if a.sigma else None), pool=a.pool, relu=a.pool)
 torch.cuda.synchronize()
 L.bt_debug_set_stamp_buffer(None)
 t = buf.cpu().tolist()
@@ -28,7 +28,7 @@ t0 = t[0]
 print("  fast: start->Wloads-issued", t[240]-t[128+6], " Xloads-issued", t[251]-t[240])
 print("producer phases st3: loads-issued", t[251]-t[250], " draws", t[252]-t[251], " W->LDS", t[253]-t[252], " X->LDS(end)", t[128+7]-t[253])
 print("s_memtime ticks (100 MHz realtime? or shader clock) relative to consumer loop start")
-print("consumer: loop", t[1] - t0, "end-of-kernel", t[126] - t0)
+print("consumer: loop", t[1] - t0, "end-of-kernel", t[126] - t0, " epilogue stamps (rel. loop end):", [v - t[1] for v in t[120:124]])
 for s in range(60):
     if t[2 + 2 * s] == 0: break
     c0, c1, p0, p1 = t[2 + 2 * s] - t0, t[3 + 2 * s] - t0, t[128 + 2 * s] - t0, t[129 + 2 * s] - t0
