@@ -42,6 +42,8 @@ static bool fast_geometry(FwdArgs& a) {
   const bool grid = a.pixel_major || (!LINEAR && a.HoWo > 1);
   // Row-chunk staging of the x patch (16-byte pieces of input rows copied straight into LDS): needs 16-byte aligned rows
   // and the slightly wider patch to fit with the same tile. Flipout stages x through registers (it multiplies by the signs).
+  static const bool no_cvec = getenv("BT_NO_XCVEC") != nullptr;  // A/B hook
+  a.x_cvec = (!no_cvec && !LINEAR && (((uintptr_t)a.x) & 15u) == 0 && (a.x_sample_stride & 3) == 0 && (((long long)a.Ci * a.HW) & 3) == 0 && (a.Cig & 3) == 0) ? 1 : 0;
   a.x_rows = 0;
   static const bool no_rows = getenv("BT_NO_XROWS") != nullptr;  // A/B hook
   if (!no_rows && !LINEAR && !FLIP && !a.pixel_major && a.HoWo > 1 && (a.W & 3) == 0 && (((uintptr_t)a.x) & 15u) == 0 && (a.x_sample_stride & 3) == 0) {
@@ -75,6 +77,16 @@ static int ensure_lds(Kern kern, int lds, bool* flags) {
   return BT_OK;
 }
 
+template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, int XMODE>
+static int launch_fast(const FwdArgs& a, hipStream_t stream) {
+  constexpr int lds = fused_lds_bytes<BN, BM, FLIP>();
+  auto fk = fused_fast_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, false, XMODE>;
+  static bool fflags[64] = {};
+  if (int rc = ensure_lds(fk, lds, fflags)) return rc;
+  hipLaunchKernelGGL(fk, dim3((unsigned)a.total_blocks), dim3(kThreads), lds, stream, a);
+  return check_launch("fused forward (fast)");
+}
+
 template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, bool INJ>
 static int launch_cfg(FwdArgs& a, hipStream_t stream) {
   constexpr int lds = fused_lds_bytes<BN, BM, FLIP>();
@@ -100,11 +112,15 @@ static int launch_cfg(FwdArgs& a, hipStream_t stream) {
   a.kl_slices = total < 256 ? (int)total : 256;  // workgroups that sweep a slice of the weights for KL (4 wave slots each)
   if constexpr (!INJ) {
     if (fast) {
-      auto fk = fused_fast_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, false>;
-      static bool fflags[64] = {};
-      if (int rc = ensure_lds(fk, lds, fflags)) return rc;
-      hipLaunchKernelGGL(fk, dim3((unsigned)total), dim3(kThreads), lds, stream, a);
-      return check_launch("fused forward (fast)");
+      // x staging mode (bt_fused_fast.h): row chunks need the wide spatial tiles, channel vectors the narrow ones
+      constexpr bool has_rows = !LINEAR && !FLIP && BM >= 128, has_cvec = !LINEAR && BM <= 128;
+      if constexpr (has_rows) {
+        if (a.x_rows) return launch_fast<BN, BM, CWN, FLIP, LINEAR, TRANS, 1>(a, stream);
+      }
+      if constexpr (has_cvec) {
+        if (a.x_cvec && (a.HW == 1 || a.HW == 4)) return launch_fast<BN, BM, CWN, FLIP, LINEAR, TRANS, 2>(a, stream);
+      }
+      return launch_fast<BN, BM, CWN, FLIP, LINEAR, TRANS, 0>(a, stream);
     }
   }
   if constexpr (BM <= 256) {

@@ -21,8 +21,14 @@ __device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t& r, float
 #endif
 }
 
-template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, bool INJ>
+// XMODE: how the conv x patch reaches LDS. 0: one dword per patch word through registers (any geometry; Linear ignores it).
+// 1: 16-byte row chunks copied global -> LDS directly (host flag x_rows; Reparameterization only). 2: 16-byte channel
+// vectors for 1x1 / 2x2 input planes when the tile's tap window allows, else as 0. One mode per instantiation keeps each
+// kernel's producer loop free of the other modes' registers and scalars.
+template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, bool INJ, int XMODE = 0>
 __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
+  static_assert(XMODE == 0 || !LINEAR, "x staging modes are for conv patches");
+  static_assert(XMODE != 1 || !FLIP, "Flipout multiplies x by its signs on the way to LDS");
   constexpr int CWM = 4 / CWN;
   constexpr int WTN = BN / CWN, WTM = BM / CWM;
   constexpr int TN = WTN / 32, TM = WTM / 32;
@@ -131,8 +137,7 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
   const int ps_h = (dymax == dymin) ? 1 : a.SH, gs_h = (dymax == dymin) ? a.SH : 1;
   // Row-chunk mode (host flag): patch rows are whole 16-byte chunks of the input rows, copied global -> LDS without passing
   // through registers; the patch keeps every input column (ps_w = stride) and starts at a multiple of 4.
-  constexpr bool kRows = !LINEAR && !FLIP;
-  const bool xrows = kRows && a.x_rows != 0;
+  constexpr bool kRows = XMODE == 1, xrows = kRows;
   const int x_lo = w0 * a.SW - a.PW + dxmin;  // input column of the first tap of the first output column
   int xa = x_lo, nchk = 0;
   if (xrows) nchk = row_chunks(x_lo, x_lo + (t_Wt - 1) * a.SW + (dxmax - dxmin), a.W, &xa);
@@ -143,6 +148,16 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
   if (!LINEAR)
     while (CC > 4 && CC * PCH > X_WORDS) CC >>= 1;  // the host guaranteed 4 * PCH <= X_WORDS
   const int lcc = 31 - __clz(CC);
+  // Channel-vector staging (XMODE 2) when this tile's tap window is the whole (tiny) input plane. The channel planes of
+  // the LDS patch are then PST words apart, padded so the vectors' LDS writes spread over all banks.
+  const int y_lo = r0 * a.SH - a.PH + dymin;  // input row of the patch origin
+  bool cvecA = XMODE == 2 && a.HW == 1 && PIMG == 1 && (Cig & 3) == 0;
+  bool cvecB = XMODE == 2 && a.HW == 4 && a.W == 2 && PIMG == 4 && PWt == 2 && x_lo == 0 && y_lo == 0 && gs_h == 1 && gs_w == 1;
+  int PST = PCH;
+  if (cvecA) PST = PCH + ((33 - (PCH & 31)) & 31);  // == 1 (mod 32): lanes = (image, channel quad) write 4 planes
+  if (cvecB) PST = PCH + ((36 - (PCH & 31)) & 31);  // == 4 (mod 32), stays a multiple of 4: lanes = (image, channel) write 16 bytes
+  if (CC * PST > X_WORDS) cvecA = cvecB = false, PST = PCH;
+  const bool cvec = cvecA || cvecB;
   const int KC = NA << lcc;  // K rows of a full stage (a multiple of 4, <= 36)
   const int NS = nA ? n_ach * ((Cig + CC - 1) / CC) : 0;
 
@@ -153,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
       int off = t * XS;
       if (!LINEAR) {
         const int4 e = taptab[a0 + (t >> lcc)];
-        off = (t & (CC - 1)) * PCH + (e.y - dymin) * PWt + (e.z - dxmin) + xshift;
+        off = (t & (CC - 1)) * PST + (e.y - dymin) * PWt + (e.z - dxmin) + xshift;
       }
       rowtab[slot * 40 + t] = off;
     }
@@ -217,11 +232,13 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
     // x patch: this thread owns plane positions ptid + 256*i (all channels of a stage)
     constexpr int PPOS = (X_WORDS / 4 + kProducers - 1) / kProducers;
     constexpr int QPOS = (X_WORDS / 16 + kProducers - 1) / kProducers;  // row-chunk mode: 16-byte chunks of one channel plane
-    int p_off[PPOS];
+    int p_off[XMODE == 1 ? 1 : PPOS];
     int q_off[kRows ? QPOS : 1];
-    const int y_lo = r0 * a.SH - a.PH + dymin;  // input row of the patch origin
+    int cv_l[XMODE == 2 ? PPOS : 1];            // channel-vector mode: LDS word of the vector's first element, -1: no slot
+    const int cv_c = cvecA ? (ptid & ((CC >> 2) - 1)) : (ptid & (CC - 1));  // this thread's channel quad / channel inside a stage
+    const int nvec = cvecA ? t_NI * (CC >> 2) : t_NI * CC;                 // 16-byte vectors per stage
     const int NCHK = t_NI * PHt * nchk + 1;     // chunks per channel plane, the closing spare included
-    if (xrows) {
+    if constexpr (xrows) {
       const int per_img = PHt * nchk;
       const uint32_t inv_img = (uint32_t)((0x100000000ull + (unsigned)per_img - 1) / (unsigned)per_img);
       const uint32_t inv_n = (uint32_t)((0x100000000ull + (unsigned)nchk - 1) / (unsigned)nchk);
@@ -236,11 +253,26 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
         const bool ok = q < NCHK - 1 && b < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
         q_off[i] = ok ? 4 * ((b * a.Ci + g * Cig) * a.HW + y * a.W + x) : (int)kOOB;  // halo chunks read (and write) zeros
       }
+    } else if (XMODE == 2 && cvec) {
+      // Tiny input planes: one 16-byte load covers 4 channels of a 1x1 input (cvecA) or the whole 2x2 plane of one channel
+      // (cvecB). Consecutive lanes take consecutive channels of ONE image -- contiguous in memory -- instead of the same
+      // channel of 64 images (one 4-byte piece out of 64 different lines per load instruction).
+      if constexpr (XMODE == 2) {
+#pragma unroll
+        for (int i = 0; i < PPOS; ++i) {
+          const int e = ptid + kProducers * i;
+          const int img = cvecA ? e >> (lcc - 2) : e >> lcc;
+          const int b = b0 + img;
+          const bool ok = img < t_NI && b < a.B;
+          p_off[i] = ok ? (cvecA ? 4 * (b * a.Ci + g * Cig + 4 * cv_c) : 16 * (b * a.Ci + g * Cig + cv_c)) : (int)kOOB;
+          cv_l[i] = img < t_NI ? (cvecA ? 4 * cv_c * PST + img : cv_c * PST + 4 * img) : -1;
+        }
+      }
     } else if (!LINEAR) {
       const uint32_t inv_pimg = (uint32_t)((0x100000000ull + (unsigned)PIMG - 1) / (unsigned)PIMG);
       const uint32_t inv_pw = (uint32_t)((0x100000000ull + (unsigned)PWt - 1) / (unsigned)PWt);
 #pragma unroll
-      for (int i = 0; i < PPOS; ++i) {
+      for (int i = 0; i < (XMODE == 1 ? 1 : PPOS); ++i) {
         const int pos = ptid + kProducers * i;
         const int pp = pos < PCH ? pos : 0;
         const int img = PIMG == 1 ? pp : (int)__umulhi((uint32_t)pp, inv_pimg);
@@ -291,7 +323,7 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
       // ---- loads: activations ----
       constexpr int RP = kProducers / 8;
       constexpr int PC = LINEAR ? 1 : (X_WORDS / CCs + kProducers - 1) / kProducers;
-      constexpr int NXR = LINEAR ? ((BM + RP - 1) / RP) * 4 : PC * CCs;
+      constexpr int NXR = LINEAR ? ((BM + RP - 1) / RP) * 4 : (PC * CCs > 4 * PPOS ? PC * CCs : 4 * PPOS);
       float xv[NXR];
       uint32_t xo[FLIP ? NXR : 1];
       if constexpr (LINEAR) {
@@ -309,8 +341,8 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
             for (int j = 0; j < 4; ++j) xo[4 * p + j] = off + j;
           }
         }
-      } else if (xrows) {
-        if constexpr (kRows) {
+      } else if constexpr (xrows) {
+        {
           if (ach == 0) {  // 16-byte row chunks, global -> LDS directly: lane l of a wave fills chunk (wave's first chunk + l)
 #pragma unroll
             for (int c = 0; c < CCs; ++c) {
@@ -320,8 +352,25 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
               for (int i = 0; i < QPOS; ++i) {
                 if (wave_u0 + kProducers * i < NCHK) {  // wave-uniform
                   if (ptid + kProducers * i < NCHK)
-                    lds_dma16(r_x, Xt0 + c * PCH + 4 * (wave_u0 + kProducers * i), chan ? q_off[i] : (int)kOOB, soff);
+                    lds_dma16(r_x, Xt0 + c * PST + 4 * (wave_u0 + kProducers * i), chan ? q_off[i] : (int)kOOB, soff);
                 }
+              }
+            }
+          }
+        }
+      } else if (XMODE == 2 && cvec) {
+        if (ach == 0) {
+          const int cbyte = c0 * (cvecA ? 4 : 16);
+          const bool chan = c0 + (cvecA ? 4 * cv_c : cv_c) < Cig;  // padded channels of the last stage read zeros
+#pragma unroll
+          for (int i = 0; i < PPOS; ++i) {
+            if (kProducers * i < nvec) {  // uniform
+              const uint32_t off = (chan && p_off[i] != (int)kOOB) ? (uint32_t)(p_off[i] + cbyte) : kOOB;
+              const float4 x4 = ldf4(r_x, off);
+              xv[4 * i] = x4.x, xv[4 * i + 1] = x4.y, xv[4 * i + 2] = x4.z, xv[4 * i + 3] = x4.w;
+              if constexpr (FLIP) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xo[4 * i + j] = (off >> 2) + j;
               }
             }
           }
@@ -379,7 +428,28 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
             }
           }
         }
-      } else if (ach == 0 && !xrows) {
+      } else if (XMODE == 2 && cvec) {
+        if (ach == 0) {
+#pragma unroll
+          for (int i = 0; i < (XMODE == 2 ? PPOS : 1); ++i) {
+            if (kProducers * i < nvec && cv_l[i] >= 0) {
+              if (cvecA) {  // 4 channels of one image: 4 planes
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  Xt0[cv_l[i] + j * PST] = xv[4 * i + j];
+                  if (FLIP) Xt1[cv_l[i] + j * PST] = __fmul_rn(xv[4 * i + j], hash_sign(skey_in, xo[4 * i + j]));
+                }
+              } else {  // the 2x2 plane of one channel: 4 consecutive patch words
+                *reinterpret_cast<float4*>(Xt0 + cv_l[i]) = make_float4(xv[4 * i], xv[4 * i + 1], xv[4 * i + 2], xv[4 * i + 3]);
+                if (FLIP)
+                  *reinterpret_cast<float4*>(Xt1 + cv_l[i]) =
+                      make_float4(__fmul_rn(xv[4 * i], hash_sign(skey_in, xo[4 * i])), __fmul_rn(xv[4 * i + 1], hash_sign(skey_in, xo[4 * i + 1])),
+                                  __fmul_rn(xv[4 * i + 2], hash_sign(skey_in, xo[4 * i + 2])), __fmul_rn(xv[4 * i + 3], hash_sign(skey_in, xo[4 * i + 3])));
+              }
+            }
+          }
+        }
+      } else if (ach == 0 && XMODE != 1) {
 #pragma unroll
         for (int i = 0; i < PC; ++i) {
           const int pos = ptid + kProducers * i;
@@ -387,8 +457,8 @@ __global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
 #pragma unroll
             for (int c = 0; c < CCs; ++c) {
               const float v = xv[i * CCs + c];
-              Xt0[c * PCH + pos] = v;
-              if (FLIP) Xt1[c * PCH + pos] = __fmul_rn(v, hash_sign(skey_in, xo[i * CCs + c]));
+              Xt0[c * PST + pos] = v;
+              if (FLIP) Xt1[c * PST + pos] = __fmul_rn(v, hash_sign(skey_in, xo[i * CCs + c]));
             }
           }
         }

@@ -51,6 +51,7 @@ struct FwdArgs {
   int n_tiles, m_tiles, total_blocks;
   int t_NI, t_R, t_Wt, n_bt, n_rt, n_ct;  // fast flavour: tile = t_NI images x t_R rows x t_Wt cols; tile grid per (n-tile, sample)
   int patch_ok;                   // host: tiles are whole images (or pixel-major), so the x operand can be staged as a patch
+  int x_cvec;                     // host (fast flavour): x is 16-byte aligned per image -> tiny planes are staged as channel vectors
   int x_rows;                     // host (fast flavour): stage the x patch as 16-byte row chunks written straight to LDS
   int pixel_major, mt_per_pixel;  // m-tile = (one output pixel, BM images) instead of BM consecutive (b, ho, wo)
   int w_vec, x_vec;               // float4 paths allowed (taps == 1, K % 4 == 0, 16-B aligned bases)

@@ -265,6 +265,12 @@ def test_lstm_reparameterization_matches_reference_golden():
     (4, 8, 1, 1, 0, 1, 300, 2, False),      # one row wider than a tile: row segments
     (3, 8, 7, 2, 3, 56, 56, 2, False),      # 7x7 stem on a larger image
     (12, 8, 3, 1, 2, 20, 24, 2, True),      # padding 2 (wide halo), Wo % 4 == 0
+    (16, 24, 3, 1, 1, 1, 1, 70, False),     # 1x1 input: x staged as 4-channel vectors (one centre tap)
+    (20, 8, 3, 1, 1, 1, 1, 33, True),       # ... Flipout, channels not a multiple of the stage width
+    (16, 24, 3, 1, 1, 2, 2, 70, False),     # 2x2 input, pixel-major tiles: x staged as whole-plane vectors
+    (12, 8, 3, 1, 1, 2, 2, 33, True),       # ... Flipout
+    (8, 16, 3, 2, 1, 2, 2, 40, False),      # 2x2 -> 1x1 (stride 2): four taps on a whole-plane patch
+    (6, 8, 3, 1, 1, 2, 2, 9, False),        # channel count that is not a multiple of 4: scalar staging
 ])
 def test_fast_kernel_tile_geometries_vs_oracle(Ci, Co, k, st, pd, H, W, B, flip):
     """Spatial sizes that exercise every tile form of the specialised kernel (whole images / row bands / row segments,
