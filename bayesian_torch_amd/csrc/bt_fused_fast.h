@@ -25,8 +25,12 @@ __device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t& r, float
 // 1: 16-byte row chunks copied global -> LDS directly (host flag x_rows; Reparameterization only). 2: 16-byte channel
 // vectors for 1x1 / 2x2 input planes when the tile's tap window allows, else as 0. One mode per instantiation keeps each
 // kernel's producer loop free of the other modes' registers and scalars.
-template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, bool INJ, int XMODE = 0>
-__global__ __launch_bounds__(kThreads) void fused_fast_kernel(const FwdArgs a) {
+// NPW: producer waves (4: one per SIMD beside its consumer wave; 8: two per SIMD -- for the narrow tiles, whose weight
+// synthesis per MFMA is the largest and whose registers allow 12 waves per workgroup).
+template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, bool INJ, int XMODE = 0, int NPW = 4>
+__global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArgs a) {
+  constexpr int kProducers = 64 * NPW;  // (shadows the general kernel's constant)
+  static_assert(NPW == 4 || (NPW == 8 && !LINEAR), "producer waves");
   static_assert(XMODE == 0 || !LINEAR, "x staging modes are for conv patches");
   static_assert(XMODE != 1 || !FLIP, "Flipout multiplies x by its signs on the way to LDS");
   constexpr int CWM = 4 / CWN;

@@ -146,29 +146,34 @@ extern "C" int bt_rng_philox_raw(uint64_t seed, const uint32_t ctr[4], uint32_t 
   return BT_OK;
 }
 
-// C <= 64 (the usual classifier head): one WAVE per batch row, lane c owns class c; no barriers, samples in fixed order.
+// C <= 64 (the usual classifier head): one WAVE per batch row, lane l owns sample 64 * chunk + l and walks the classes
+// itself (no cross-lane work for the softmax); per-class sums over the samples are butterfly reductions, fixed order.
 __global__ __launch_bounds__(256) void mc_epilogue_small_kernel(int S, int B, int C, const float* __restrict__ logits, float* __restrict__ packed) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
-  const bool on = lane < C;
-  float psum = 0.f, lsum = 0.f, ent_total = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const float x = on ? logits[((long long)s * B + b) * C + lane] : -INFINITY;
-    float mx = x;
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    const float z = x - mx;
-    const float e = on ? expf(z) : 0.f;
-    float den = e;
-    for (int o = 32; o > 0; o >>= 1) den += __shfl_xor(den, o, 64);
+  float psum = 0.f, lsum = 0.f, ent_total = 0.f;  // lane c accumulates class c
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const bool on = s < S;
+    const float* row = logits + ((long long)(on ? s : 0) * B + b) * C;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, row[c]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(row[c] - mx);
     const float lden = logf(den);
-    const float p = e / den;
-    psum += p;
-    lsum += on ? x : 0.f;
-    float ent = (on && p > 0.f) ? -p * (z - lden) : 0.f;
+    float ent = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float x = row[c], z = x - mx, p = expf(z) / den;
+      ent -= (p > 0.f) ? p * (z - lden) : 0.f;
+      float ps = on ? p : 0.f, ls = on ? x : 0.f;
+      for (int o = 32; o > 0; o >>= 1) ps += __shfl_xor(ps, o, 64), ls += __shfl_xor(ls, o, 64);
+      if (lane == c) psum += ps, lsum += ls;
+    }
+    ent = on ? ent : 0.f;
     for (int o = 32; o > 0; o >>= 1) ent += __shfl_xor(ent, o, 64);
     ent_total += ent;
   }
-  if (on) {
+  if (lane < C) {
     packed[(long long)b * C + lane] = psum;
     packed[(long long)B * C + B + (long long)b * C + lane] = lsum;
   }

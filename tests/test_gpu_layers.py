@@ -167,7 +167,7 @@ def test_mc_epilogue_matches_oracle():
     from oracle import bt_oracle as O
     from bayesian_torch_amd import functional as F
     torch.manual_seed(3)
-    for (S, B, Cc) in [(5, 7, 10), (3, 4, 1000)]:
+    for (S, B, Cc) in [(5, 7, 10), (3, 4, 1000), (70, 9, 64), (32, 128, 10)]:
         logits = torch.randn(S, B, Cc) * 4
         packed = F.mc_epilogue(logits.cuda()).cpu()
         p, e, l = O.mc_epilogue_ref(logits)
