@@ -751,23 +751,36 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
           if (stamp) a.dbg[121 + 2 * i] = __builtin_amdgcn_s_memtime();
           continue;
         }
-        // read-out: quad c = (row, 4 positions); consecutive threads take consecutive quads of a row
-        constexpr int QROW = BM / 4, NQ = SROWS * QROW;
-#pragma unroll 4
-        for (int c = tid; c < NQ; c += 256) {
-          const int row = c / QROW, m4 = c - row * QROW;
-          int bq, hq, wq;
-          const bool mok = col_decode(4 * m4, bq, hq, wq);
-          const int co_l = (row >> 5) * WTN + i * 32 + (row & 31);
-          if (mok && n0 + co_l < a.Cog) {
-            const uint32_t oidx = (uint32_t)(((bq * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hq) * a.Wo + wq);
-            float4 v = *reinterpret_cast<const float4*>(stage + row * SROW + 4 * m4);
-            if (res_s) {
-              const float4 r4 = *reinterpret_cast<const float4*>(res_s + oidx);
-              v.x = __fadd_rn(v.x, r4.x), v.y = __fadd_rn(v.y, r4.y), v.z = __fadd_rn(v.z, r4.z), v.w = __fadd_rn(v.w, r4.w);
-            }
-            if (relu) v.x = v.x < 0.f ? 0.f : v.x, v.y = v.y < 0.f ? 0.f : v.y, v.z = v.z < 0.f ? 0.f : v.z, v.w = v.w < 0.f ? 0.f : v.w;
-            *reinterpret_cast<float4*>(out_s + oidx) = v;
+        // read-out: quad c = (row, 4 positions); consecutive threads take consecutive quads of a row. Batches of U quads:
+        // all residual loads and LDS reads of a batch are issued (at clamped addresses, no branches) before the first use.
+        constexpr int QROW = BM / 4, NQ = SROWS * QROW, NIT = NQ / 256, U = NIT < 8 ? NIT : 8;
+        static_assert(NQ % 256 == 0 && NIT % U == 0, "read-out batches");
+        for (int c0q = tid; c0q < NQ; c0q += 256 * U) {
+          uint32_t oidx[U];
+          bool okq[U];
+          float4 v[U], r4[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int c = c0q + 256 * u;
+            const int row = c / QROW, m4 = c - row * QROW;
+            int bq, hq, wq;
+            const bool mok = col_decode(4 * m4, bq, hq, wq);
+            const int co_l = (row >> 5) * WTN + i * 32 + (row & 31);
+            okq[u] = mok && n0 + co_l < a.Cog;
+            oidx[u] = okq[u] ? (uint32_t)(((bq * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hq) * a.Wo + wq) : 0u;
+            v[u] = *reinterpret_cast<const float4*>(stage + row * SROW + 4 * m4);
+          }
+          if (res_s) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) r4[u] = *reinterpret_cast<const float4*>(res_s + oidx[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+              v[u].x = __fadd_rn(v[u].x, r4[u].x), v[u].y = __fadd_rn(v[u].y, r4[u].y), v[u].z = __fadd_rn(v[u].z, r4[u].z), v[u].w = __fadd_rn(v[u].w, r4[u].w);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (relu) v[u].x = v[u].x < 0.f ? 0.f : v[u].x, v[u].y = v[u].y < 0.f ? 0.f : v[u].y, v[u].z = v[u].z < 0.f ? 0.f : v[u].z, v[u].w = v[u].w < 0.f ? 0.f : v[u].w;
+            if (okq[u]) *reinterpret_cast<float4*>(out_s + oidx[u]) = v[u];
           }
         }
       }
