@@ -202,6 +202,51 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
   float* const osh = smem + 3 * BN;
   const bool kl_block = a.do_kl && (int)blockIdx.x < a.kl_slices;
 
+  // ---- output side, shared by both arms -------------------------------------------------------------------------------------
+  float* const out_s = a.out + (long long)s * a.out_elems;
+  const float* const res_s = a.ep_res ? a.ep_res + (long long)s * a.ep_res_stride : nullptr;
+  const bool relu = a.ep_relu != 0;
+  // Read-out of one staged pass of the output tile (see the consumers' output stage): quad c = (channel row, 4 positions),
+  // consecutive threads on consecutive quads of a row -> whole 128-byte lines per store and per residual load. EVERY thread
+  // of the workgroup takes part (the producers have nothing else left to do). Batches of U quads: all residual loads and
+  // LDS reads of a batch are issued (at clamped addresses, no branches) before the first use.
+  // (Only in the row-chunk instantiations -- the wide spatial tiles, where the output stage is 8 % of a workgroup's life;
+  // elsewhere the extra code in the producer arm costs the main loop more than the read-out gains.)
+  constexpr bool kReadoutAll = XMODE == 1;
+  auto readout_quads = [&](int i, int t0) {
+    constexpr int SROW = BM + 4, SROWS = 32 * CWN, QROW = BM / 4, NQ = SROWS * QROW, NT = kReadoutAll ? 256 + kProducers : 256;
+    constexpr int NITc = (NQ + NT - 1) / NT, U = NITc < 8 ? NITc : 8;
+    const float* const stage = smem + 4 * BN;
+    for (int c0q = t0; c0q < NQ; c0q += NT * U) {
+      uint32_t oidx[U];
+      bool okq[U];
+      float4 v[U], r4[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int cr = c0q + NT * u, c = cr < NQ ? cr : 0;
+        const int row = c / QROW, m4 = c - row * QROW;
+        int bq, hq, wq;
+        const bool mok = col_decode(4 * m4, bq, hq, wq);
+        const int co_l = (row >> 5) * WTN + i * 32 + (row & 31);
+        okq[u] = cr < NQ && mok && n0 + co_l < a.Cog;
+        oidx[u] = okq[u] ? (uint32_t)(((bq * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hq) * a.Wo + wq) : 0u;
+        v[u] = *reinterpret_cast<const float4*>(stage + row * SROW + 4 * m4);
+      }
+      if (res_s) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) r4[u] = *reinterpret_cast<const float4*>(res_s + oidx[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          v[u].x = __fadd_rn(v[u].x, r4[u].x), v[u].y = __fadd_rn(v[u].y, r4[u].y), v[u].z = __fadd_rn(v[u].z, r4[u].z), v[u].w = __fadd_rn(v[u].w, r4[u].w);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (relu) v[u].x = v[u].x < 0.f ? 0.f : v[u].x, v[u].y = v[u].y < 0.f ? 0.f : v[u].y, v[u].z = v[u].z < 0.f ? 0.f : v[u].z, v[u].w = v[u].w < 0.f ? 0.f : v[u].w;
+        if (okq[u]) *reinterpret_cast<float4*>(out_s + oidx[u]) = v[u];
+      }
+    }
+  };
+
   if (producer) {
     // Producer instructions win issue arbitration over the consumer wave of the same SIMD: their VALU work slots in
     // between MFMAs instead of waiting for the consumer to stall.
@@ -514,8 +559,18 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
       osh[ptid] = cv ? sh : 0.f;
     }
     __syncthreads();
-    if (TRANS && a.out_vec4) {  // the consumers pass the output tile through LDS: keep them company at their barriers
-      for (int i = 0; i < 2 * TN - 1; ++i) __syncthreads();
+    if (TRANS && a.out_vec4) {  // the consumers pass the output tile through LDS: same barriers ...
+      if constexpr (kReadoutAll) {  // ... and a share of the read-out
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          if (i > 0) __syncthreads();
+          __syncthreads();
+          if (!a.ep_pool) readout_quads(i, tid);
+        }
+      } else {
+        for (int i = 0; i < 2 * TN - 1; ++i) __syncthreads();
+      }
     }
   } else {
     // =================================================== CONSUMERS ===========================================================
@@ -664,10 +719,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
     __syncthreads();  // the producers have staged bias / output-stage constants
 
     // ---- output stage + store ----
-    float* const out_s = a.out + (long long)s * a.out_elems;
     const float* const sout_s = (FLIP && INJ) ? a.sign_out + (long long)s * a.out_elems : nullptr;
-    const float* const res_s = a.ep_res ? a.ep_res + (long long)s * a.ep_res_stride : nullptr;
-    const bool relu = a.ep_relu != 0;
     if (TRANS && a.out_vec4) {
       // Spatial NCHW output. The accumulators come out of the D[m][co] orientation with a lane owning ONE output channel
       // (bias / scale / shift are lane constants) and registers 4q..4q+3 holding 4 consecutive output positions; stored
@@ -788,38 +840,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
           if (stamp) a.dbg[121 + 2 * i] = __builtin_amdgcn_s_memtime();
           continue;
         }
-        // read-out: quad c = (row, 4 positions); consecutive threads take consecutive quads of a row. Batches of U quads:
-        // all residual loads and LDS reads of a batch are issued (at clamped addresses, no branches) before the first use.
-        constexpr int QROW = BM / 4, NQ = SROWS * QROW, NIT = NQ / 256, U = NIT < 8 ? NIT : 8;
-        static_assert(NQ % 256 == 0 && NIT % U == 0, "read-out batches");
-        for (int c0q = tid; c0q < NQ; c0q += 256 * U) {
-          uint32_t oidx[U];
-          bool okq[U];
-          float4 v[U], r4[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int c = c0q + 256 * u;
-            const int row = c / QROW, m4 = c - row * QROW;
-            int bq, hq, wq;
-            const bool mok = col_decode(4 * m4, bq, hq, wq);
-            const int co_l = (row >> 5) * WTN + i * 32 + (row & 31);
-            okq[u] = mok && n0 + co_l < a.Cog;
-            oidx[u] = okq[u] ? (uint32_t)(((bq * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hq) * a.Wo + wq) : 0u;
-            v[u] = *reinterpret_cast<const float4*>(stage + row * SROW + 4 * m4);
-          }
-          if (res_s) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) r4[u] = *reinterpret_cast<const float4*>(res_s + oidx[u]);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-              v[u].x = __fadd_rn(v[u].x, r4[u].x), v[u].y = __fadd_rn(v[u].y, r4[u].y), v[u].z = __fadd_rn(v[u].z, r4[u].z), v[u].w = __fadd_rn(v[u].w, r4[u].w);
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            if (relu) v[u].x = v[u].x < 0.f ? 0.f : v[u].x, v[u].y = v[u].y < 0.f ? 0.f : v[u].y, v[u].z = v[u].z < 0.f ? 0.f : v[u].z, v[u].w = v[u].w < 0.f ? 0.f : v[u].w;
-            if (okq[u]) *reinterpret_cast<float4*>(out_s + oidx[u]) = v[u];
-          }
-        }
+        readout_quads(i, tid);
       }
     } else {
   #pragma unroll
