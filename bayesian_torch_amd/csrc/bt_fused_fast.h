@@ -48,6 +48,9 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
   int* const misc = reinterpret_cast<int*>(red + 12);
   int* const rowtab = misc + 8;
 
+  // s_memtime stage stamps (tools/stamps.py) exist only in a diagnostic build (make STAMPS=1): in the product build the
+  // pointer is a constant null and every stamp, its predicate and its scalar registers fold away.
+  unsigned long long* const dbg_ = kStamps ? a.dbg : nullptr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool producer = wave >= 4;
   const int ptid = producer ? tid - 256 : tid;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
   if (producer) {
     // Producer instructions win issue arbitration over the consumer wave of the same SIMD: their VALU work slots in
     // between MFMAs instead of waiting for the consumer to stall.
-    if (!a.dbg || a.dbg[200] == 0) __builtin_amdgcn_s_setprio(3);
+    if (!dbg_ || dbg_[200] == 0) __builtin_amdgcn_s_setprio(3);
     // =================================================== PRODUCERS ===========================================================
     // ---- per-thread state, decoded once ----
     constexpr int UMAX = (BN * 9 + kProducers - 1) / kProducers;
@@ -367,8 +370,8 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
           rs[i][0] = r4.x, rs[i][1] = r4.y, rs[i][2] = r4.z, rs[i][3] = r4.w;
         }
       }
-      const bool pst = a.dbg && blockIdx.x == 0 && tid == 256 && st == 3;
-      if (pst) a.dbg[251 - 11] = __builtin_amdgcn_s_memtime();
+      const bool pst = dbg_ && blockIdx.x == 0 && tid == 256 && st == 3;
+      if (pst) dbg_[251 - 11] = __builtin_amdgcn_s_memtime();
       // ---- loads: activations ----
       constexpr int RP = kProducers / 8;
       constexpr int PC = LINEAR ? 1 : (X_WORDS / CCs + kProducers - 1) / kProducers;
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
           }
         }
       }
-      if (pst) a.dbg[251] = __builtin_amdgcn_s_memtime();
+      if (pst) dbg_[251] = __builtin_amdgcn_s_memtime();
       // ---- draws (no load feeds them) ----
       if constexpr (!INJ) {
 #pragma unroll
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
           if (i == 0 || wave_u0 + kProducers * i < nunits)  // wave-uniform only: masked lanes cost nothing, and without per-lane
             philox_normal4(key_w, sample, (e_off[i] + tap_e[i] + (uint32_t)c0) >> 2, ep[i]);  // branches the units' chains interleave
       }
-      if (pst) a.dbg[252] = __builtin_amdgcn_s_memtime();
+      if (pst) dbg_[252] = __builtin_amdgcn_s_memtime();
       // ---- sampled weights -> LDS ----
 #pragma unroll
       for (int i = 0; i < UMAX; ++i) {
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
           }
         }
       }
-      if (pst) a.dbg[253] = __builtin_amdgcn_s_memtime();
+      if (pst) dbg_[253] = __builtin_amdgcn_s_memtime();
       // ---- activations -> LDS ----
       if constexpr (LINEAR) {
         const int kq = ptid & 7, mr = ptid >> 3;
@@ -514,12 +517,12 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
       }
     };
 
-    const bool stamp = a.dbg && blockIdx.x == 0 && tid == 256;
+    const bool stamp = dbg_ && blockIdx.x == 0 && tid == 256;
     auto run_stages = [&](auto LCCc) {  // one loop per channel-chunk width: each carries only its own loop invariants
       for (int st = 0; st <= NS; ++st) {  // NS + 1 barriers, like the consumer arm
-        if (stamp && st < 60) a.dbg[128 + 2 * st] = __builtin_amdgcn_s_memtime();
+        if (stamp && st < 60) dbg_[128 + 2 * st] = __builtin_amdgcn_s_memtime();
         if (st < NS) produce(LCCc, st);
-        if (stamp && st < 60) a.dbg[128 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
+        if (stamp && st < 60) dbg_[128 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
         __syncthreads();
       }
     };
@@ -648,10 +651,10 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[w][i][j][r] = 0.f;
 
-    const bool stamp = a.dbg && blockIdx.x == 0 && tid == 0;
-    if (stamp) a.dbg[0] = __builtin_amdgcn_s_memtime();
+    const bool stamp = dbg_ && blockIdx.x == 0 && tid == 0;
+    if (stamp) dbg_[0] = __builtin_amdgcn_s_memtime();
     for (int st = 0; st < NS; ++st) {
-      if (stamp && st < 60) a.dbg[2 + 2 * st] = __builtin_amdgcn_s_memtime();
+      if (stamp && st < 60) dbg_[2 + 2 * st] = __builtin_amdgcn_s_memtime();
       const int cch = n_ach == 1 ? st : st / n_ach;
       int KCs = KC;  // K rows of this stage
       if (n_ach > 1) {
@@ -712,10 +715,10 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
       step_pair(std::integral_constant<int, 12>{});
       step_pair(std::integral_constant<int, 14>{});
       step_pair(std::integral_constant<int, 16>{});
-      if (stamp && st < 60) a.dbg[2 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
+      if (stamp && st < 60) dbg_[2 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
       __syncthreads();
     }
-    if (stamp) a.dbg[1] = __builtin_amdgcn_s_memtime();
+    if (stamp) dbg_[1] = __builtin_amdgcn_s_memtime();
     __syncthreads();  // the producers have staged bias / output-stage constants
 
     // ---- output stage + store ----
@@ -766,7 +769,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
           }
         }
         __syncthreads();
-        if (stamp) a.dbg[120 + 2 * i] = __builtin_amdgcn_s_memtime();
+        if (stamp) dbg_[120 + 2 * i] = __builtin_amdgcn_s_memtime();
         if (a.ep_pool) {
           // fused MaxPool2d(3, 2, 1) of whole staged images (tile column = (img * Ho + ho) * Wo + wo); NaN wins like torch's
           const int Hp = a.ep_Hp, Wp = a.ep_Wp, PP = Hp * Wp, per_row = t_NI * PP;
@@ -804,7 +807,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
                 if (ok) oplane[py * Wp + px] = m;
               }
             }
-            if (stamp) a.dbg[121 + 2 * i] = __builtin_amdgcn_s_memtime();
+            if (stamp) dbg_[121 + 2 * i] = __builtin_amdgcn_s_memtime();
             continue;
           }
           const uint32_t inv_row = (uint32_t)((0x100000000ull + (unsigned)per_row - 1) / (unsigned)per_row);
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
               out_s[((b * a.Co + g * a.Cog + n0 + co_l) * Hp + py) * Wp + px] = m;
             }
           }
-          if (stamp) a.dbg[121 + 2 * i] = __builtin_amdgcn_s_memtime();
+          if (stamp) dbg_[121 + 2 * i] = __builtin_amdgcn_s_memtime();
           continue;
         }
         readout_quads(i, tid);
@@ -896,7 +899,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
     }
   }
 
-  if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[126] = __builtin_amdgcn_s_memtime();
+  if (dbg_ && blockIdx.x == 0 && tid == 0) dbg_[126] = __builtin_amdgcn_s_memtime();
 }
 
 }  // namespace bt

@@ -34,6 +34,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBK = 36;        // K rows of one LDS stage (9 taps x 4 channels)
 constexpr int kMaxTaps = 128;  // kh*kw supported by the tap table
+#ifndef BT_STAMPS
+#define BT_STAMPS 0  // make STAMPS=1: diagnostic build with in-kernel stage stamps
+#endif
+constexpr bool kStamps = BT_STAMPS != 0;
 constexpr int kThreads = 512;   // 4 consumer waves + 4 producer waves: one of each per SIMD
 constexpr int kProducers = 256;
 
@@ -116,6 +120,7 @@ __device__ __forceinline__ double block_sum_all(double v, double* scratch) {  //
 // 1x1 convolution over a 1x1 image, which is the same memory layout.
 template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, bool INJ>
 __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
+  unsigned long long* const dbg_ = kStamps ? a.dbg : nullptr;  // stage stamps: diagnostic build only (make STAMPS=1)
   constexpr int CWM = 4 / CWN;
   constexpr int WTN = BN / CWN, WTM = BM / CWM;
   constexpr int TN = WTN / 32, TM = WTM / 32;
@@ -356,10 +361,10 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
     const int cch = st / n_ach, ach = st - cch * n_ach;
     const int a0 = ach * NA, c0 = cch * CCs;
     const int na_s = (nA - a0) < NA ? (nA - a0) : NA;
-    const bool pst = a.dbg && blockIdx.x == 0 && tid == 256 && st == 3;
-    if (pst) a.dbg[250] = __builtin_amdgcn_s_memtime();
+    const bool pst = dbg_ && blockIdx.x == 0 && tid == 256 && st == 3;
+    if (pst) dbg_[250] = __builtin_amdgcn_s_memtime();
     if (!LINEAR && n_ach > 1) setup_taps(a0, na_s);
-    if (pst) a.dbg[239] = __builtin_amdgcn_s_memtime();
+    if (pst) dbg_[239] = __builtin_amdgcn_s_memtime();
     // -------- weights: loads -----------------------------------------------------------------------------------------------
     float mu[UMAX][4], rs[UMAX][4], ep[UMAX][4];
     uint32_t ue0[UMAX];
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
         }
       }
     }
-    if (pst) a.dbg[240] = __builtin_amdgcn_s_memtime();
+    if (pst) dbg_[240] = __builtin_amdgcn_s_memtime();
     // -------- K-row table of this stage's x tile (consumers: address = rowtab[k row] + colbase[lane]) ------------------------
     {
       int* const rt = rowtab + (st & 1) * 40;
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
         rt[ptid] = off;
       }
     }
-    if (pst) a.dbg[241] = __builtin_amdgcn_s_memtime();
+    if (pst) dbg_[241] = __builtin_amdgcn_s_memtime();
     // -------- activations: loads --------------------------------------------------------------------------------------------
     constexpr bool FASTX = !LINEAR && (NG <= 4);                   // static (tap, channel) nest; NG <= 4 <= CC
     constexpr int CPT = FASTX ? CCs / NG : 1;                      // channels per (thread, tap)
@@ -499,14 +504,14 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
         }
       }
     }
-    if (pst) a.dbg[251] = __builtin_amdgcn_s_memtime();
+    if (pst) dbg_[251] = __builtin_amdgcn_s_memtime();
     // -------- draws (independent of every load above) ----------------------------------------------------------------------
     if constexpr (!INJ) {
 #pragma unroll
       for (int i = 0; i < UMAX; ++i)
         if (uval[i]) philox_normal4(key_w, sample, ue0[i] >> 2, ep[i]);
     }
-    if (pst) a.dbg[252] = __builtin_amdgcn_s_memtime();
+    if (pst) dbg_[252] = __builtin_amdgcn_s_memtime();
     // -------- sampled weights -> LDS (transposed) ---------------------------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < UMAX; ++i) {
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
         }
       }
     }
-    if (pst) a.dbg[253] = __builtin_amdgcn_s_memtime();
+    if (pst) dbg_[253] = __builtin_amdgcn_s_memtime();
     // -------- activations -> LDS -------------------------------------------------------------------------------------------------
     if constexpr (LINEAR) {
       const int kq = ptid & 7, mr = ptid >> 3;
@@ -646,14 +651,14 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
   // The two roles are separate control-flow arms with the same number of workgroup barriers, so the accumulator
   // registers live only in the consumer arm and the producer arm gets the whole register budget for loads in flight.
   if (producer) {
-    const bool stamp = a.dbg && blockIdx.x == 0 && tid == 256;
+    const bool stamp = dbg_ && blockIdx.x == 0 && tid == 256;
     for (int st = 0; st <= NS; ++st) {  // NS + 1 barriers, like the consumer arm
-      if (stamp && st < 60) a.dbg[128 + 2 * st] = __builtin_amdgcn_s_memtime();
+      if (stamp && st < 60) dbg_[128 + 2 * st] = __builtin_amdgcn_s_memtime();
       if (st < NS) produce_stage(st, (st & 1) ? buf1 : buf0);
-      if (stamp && st < 60) a.dbg[128 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
+      if (stamp && st < 60) dbg_[128 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
       __syncthreads();
     }
-    if (stamp) a.dbg[127] = __builtin_amdgcn_s_memtime();
+    if (stamp) dbg_[127] = __builtin_amdgcn_s_memtime();
     // bias draw for this workgroup's output channels
     if (ptid < BN) {
       float b0 = 0.f, b1 = 0.f;
@@ -739,15 +744,15 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
         for (int j = 0; j < TM; ++j)
   #pragma unroll
           for (int r = 0; r < 16; ++r) acc[w][i][j][r] = 0.f;
-    const bool stamp = a.dbg && blockIdx.x == 0 && tid == 0;
-    if (stamp) a.dbg[0] = __builtin_amdgcn_s_memtime();
+    const bool stamp = dbg_ && blockIdx.x == 0 && tid == 0;
+    if (stamp) dbg_[0] = __builtin_amdgcn_s_memtime();
     for (int st = 0; st < NS; ++st) {  // one barrier per stage
-      if (stamp && st < 60) a.dbg[2 + 2 * st] = __builtin_amdgcn_s_memtime();
+      if (stamp && st < 60) dbg_[2 + 2 * st] = __builtin_amdgcn_s_memtime();
       consume(acc, st, (st & 1) ? buf1 : buf0);
-      if (stamp && st < 60) a.dbg[2 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
+      if (stamp && st < 60) dbg_[2 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
       __syncthreads();
     }
-    if (stamp) a.dbg[1] = __builtin_amdgcn_s_memtime();
+    if (stamp) dbg_[1] = __builtin_amdgcn_s_memtime();
     __syncthreads();  // the producers have staged the bias
 
     // output stage + store
@@ -854,7 +859,7 @@ __global__ __launch_bounds__(kThreads) void fused_fwd_kernel(const FwdArgs a) {
     }
   }
 
-  if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[126] = __builtin_amdgcn_s_memtime();
+  if (dbg_ && blockIdx.x == 0 && tid == 0) dbg_[126] = __builtin_amdgcn_s_memtime();
 }
 
 }  // namespace bt

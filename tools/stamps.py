@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-stage timeline of block 0 (diagnostic build hook bt_debug_set_stamp_buffer)."""
+"""Per-stage timeline of block 0 (hook bt_debug_set_stamp_buffer). Needs the diagnostic build:
+   make -C bayesian_torch_amd/csrc clean && make -C bayesian_torch_amd/csrc -j8 STAMPS=1   (rebuild without STAMPS afterwards)."""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
