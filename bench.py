@@ -244,7 +244,7 @@ def main():
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload=w["desc"], mc_samples_per_gpu_per_step=S, global_samples_per_step=S * world, batch=B,
                                 rng="on-chip philox", parallelism=f"mc{world}", kl="fused into forward kernels",
-                                output_stage="bn+relu+residual folded into conv epilogue" if fused else "separate torch modules",
+                                output_stage="bn+relu+residual (+ the stem max-pool) folded into the conv kernels" if fused else "separate torch modules",
                                 launch="hip graph replay" if graph is not None else "eager"),
                     roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))
