@@ -252,3 +252,56 @@ def test_resnet50_topology_cfg5_shape_family(btype):
                 rm.inject = {k: v[s].cpu() for k, v in d.items()}
             assert_close(logits[s].cpu(), ref(x), 2e-4, 2e-5, f"resnet50 {btype} sample {s}")
     assert_close(kl.cpu(), O.ref_get_kl_loss(ref), 1e-5, 0, "kl")
+
+
+def test_full_size_cfg3_properties():
+    """BASELINE cfg3 at its full size (ResNet18 width 64, CIFAR batch 128, fused output stages, the kernels bench.py times):
+    size-independent properties instead of an oracle run. (a) MC-sample independence of the launch split: 8 samples in one
+    launch == 4 + 4 == 8 x 1 with the same global sample ids, bit for bit; (b) determinism: same (seed, call) twice is
+    identical, the next call differs; (c) the fused KL equals the standalone bt_kl_normal launch over the model (get_kl_loss)
+    and does not depend on S; (d) the fused model equals the unfused module sequence (BatchNorm / ReLU / add / MaxPool as
+    torch modules) on the same draws within the layer tolerance; (e) batch-row independence: the first 32 images alone give
+    the same logits for those rows (different tile geometry) within tolerance."""
+    from bayesian_torch_amd import rng
+    from bayesian_torch_amd.harness import resnet as H
+    from bayesian_torch_amd.mc import mc_forward
+    from bayesian_torch_amd.models.dnn_to_bnn import dnn_to_bnn, get_kl_loss
+    torch.manual_seed(3)
+    net = H.resnet18(10, 64)
+    dnn_to_bnn(net, dict(PRIOR, type="Reparameterization"))
+    H.fill_bayes_params(net, 3)
+    net = net.cuda().eval()
+    x = torch.randn(128, 3, 32, 32, generator=torch.Generator().manual_seed(4)).cuda()
+    rng.set_mode("philox")
+    rng.manual_seed(123)
+    c0 = rng.peek_call()
+
+    def run(model, S, sample0, xx=x):
+        rng.set_call(c0)
+        return mc_forward(model, xx, S, sample0=sample0, with_kl=True)
+
+    plain, kl_plain = run(net, 8, 16)                       # unfused: BN / ReLU / add / MaxPool as torch modules
+    H.fuse_inference(net)
+    full, kl8 = run(net, 8, 16)
+    assert torch.isfinite(full).all() and full.shape == (8, 128, 10)
+    # (d)
+    assert_close(full.cpu(), plain.cpu(), 1e-4, 1e-5, "fused vs unfused model")
+    assert abs(float(kl8) - float(kl_plain)) <= 1e-6 * abs(float(kl_plain))
+    # (a)
+    halves = torch.cat([run(net, 4, 16)[0], run(net, 4, 20)[0]])
+    assert torch.equal(halves, full)
+    ones = torch.cat([run(net, 1, 16 + s)[0] for s in range(8)])
+    assert torch.equal(ones, full)
+    # (b)
+    again, _ = run(net, 8, 16)
+    assert torch.equal(again, full)
+    later, _ = mc_forward(net, x, 8, sample0=16, with_kl=True)   # the call counter has advanced
+    assert not torch.equal(later, full)
+    # (c)
+    kl1 = run(net, 1, 0)[1]
+    assert float(kl1) == float(kl8)
+    ref_kl = get_kl_loss(net).detach()
+    assert abs(float(kl8) - float(ref_kl)) <= 1e-5 * abs(float(ref_kl))
+    # (e)
+    part, _ = run(net, 8, 16, x[:32].contiguous())
+    assert_close(part.cpu(), full[:, :32].cpu(), 1e-4, 1e-5, "batch rows are independent of the tile geometry")
