@@ -250,6 +250,47 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
     }
   };
 
+  // Pooled read-out of one staged pass, fused MaxPool2d(3, 2, 1), for power-of-two pooled widths (the 32x32-input stem:
+  // 16 -> 8): a wave = Wp pooled columns x 64/Wp staged planes (consecutive channels: their LDS rows are 4 banks apart),
+  // walking the pooled rows. Window geometry is lane state decoded once; a window row is one 8-byte read (columns 2px,
+  // 2px+1) plus the left neighbour. NaN wins, like torch's kernel. Shared by all waves where the quads read-out is.
+  const bool pool_pow2 = a.ep_pool && (a.ep_Wp & (a.ep_Wp - 1)) == 0 && a.ep_Wp >= 4 && a.ep_Wp <= 16;
+  auto readout_pool = [&](int i, int wv) {
+    constexpr int SROW = BM + 4, SROWS = 32 * CWN, NWV = kReadoutAll ? 4 + NPW : 4;
+    const float* const stage = smem + 4 * BN;
+    auto nmax = [](float m, float v) { return (v > m || v != v) ? v : m; };
+    const int Hp = a.ep_Hp, Wp = a.ep_Wp, PP = Hp * Wp;
+    const int lwp = 31 - __clz(Wp), ppw = 64 >> lwp;
+    const int px = lane & (Wp - 1), psub = lane >> lwp;
+    const bool has_l = px > 0;
+    const int xl = has_l ? 2 * px - 1 : 0;
+    for (int q0 = wv * ppw; q0 < SROWS * t_NI; q0 += NWV * ppw) {
+      const int q = q0 + psub;
+      const int img = q / SROWS, row = q - img * SROWS;  // planes of one image are consecutive: channel fastest
+      const int co_l = (row >> 5) * WTN + i * 32 + (row & 31), b = b0 + img;
+      const bool ok = q < SROWS * t_NI && b < a.B && n0 + co_l < a.Cog;
+      const float* const plane = stage + (ok ? row * SROW + img * RW : 0);
+      float* const oplane = out_s + (ok ? (b * a.Co + g * a.Cog + n0 + co_l) * PP : 0);
+#pragma unroll 2
+      for (int py = 0; py < Hp; ++py) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int y = 2 * py - 1 + dy;
+          const bool iny = (unsigned)y < (unsigned)a.Ho;
+          const float* const rowp = plane + (iny ? y : 0) * a.Wo;
+          const float2 cd = *reinterpret_cast<const float2*>(rowp + 2 * px);
+          const float l = rowp[xl];
+          m = nmax(m, (iny && has_l) ? l : -INFINITY);
+          m = nmax(m, iny ? cd.x : -INFINITY);
+          m = nmax(m, iny ? cd.y : -INFINITY);
+        }
+        if (relu) m = m < 0.f ? 0.f : m;  // max and ReLU commute
+        if (ok) oplane[py * Wp + px] = m;
+      }
+    }
+  };
+
   if (producer) {
     // Producer instructions win issue arbitration over the consumer wave of the same SIMD: their VALU work slots in
     // between MFMAs instead of waiting for the consumer to stall.
@@ -570,6 +611,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
           if (i > 0) __syncthreads();
           __syncthreads();
           if (!a.ep_pool) readout_quads(i, tid);
+          else if (pool_pow2) readout_pool(i, wave);
         }
       } else {
         for (int i = 0; i < 2 * TN - 1; ++i) __syncthreads();
@@ -773,40 +815,8 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
         if (a.ep_pool) {
           // fused MaxPool2d(3, 2, 1) of whole staged images (tile column = (img * Ho + ho) * Wo + wo); NaN wins like torch's
           const int Hp = a.ep_Hp, Wp = a.ep_Wp, PP = Hp * Wp, per_row = t_NI * PP;
-          if ((Wp & (Wp - 1)) == 0 && Wp >= 4 && Wp <= 16) {
-            // Power-of-two pooled widths (the 32x32-input stem: 16 -> 8): a wave = Wp pooled columns x 64/Wp staged planes
-            // (consecutive channels: their LDS rows are 4 banks apart), walking the pooled rows. Window geometry is lane state
-            // decoded once; a window row is one 8-byte read (columns 2px, 2px+1) plus the left neighbour.
-            auto nmax = [](float m, float v) { return (v > m || v != v) ? v : m; };  // NaN wins, like torch's kernel
-            const int lwp = 31 - __clz(Wp), ppw = 64 >> lwp;
-            const int px = lane & (Wp - 1), psub = lane >> lwp;
-            const bool has_l = px > 0;
-            const int xl = has_l ? 2 * px - 1 : 0;
-            for (int q0 = wave * ppw; q0 < SROWS * t_NI; q0 += 4 * ppw) {
-              const int q = q0 + psub;
-              const int img = q / SROWS, row = q - img * SROWS;  // planes of one image are consecutive: channel fastest
-              const int co_l = (row >> 5) * WTN + i * 32 + (row & 31), b = b0 + img;
-              const bool ok = q < SROWS * t_NI && b < a.B && n0 + co_l < a.Cog;
-              const float* const plane = stage + (ok ? row * SROW + img * RW : 0);
-              float* const oplane = out_s + (ok ? (b * a.Co + g * a.Cog + n0 + co_l) * PP : 0);
-#pragma unroll 2
-              for (int py = 0; py < Hp; ++py) {
-                float m = -INFINITY;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                  const int y = 2 * py - 1 + dy;
-                  const bool iny = (unsigned)y < (unsigned)a.Ho;
-                  const float* const rowp = plane + (iny ? y : 0) * a.Wo;
-                  const float2 cd = *reinterpret_cast<const float2*>(rowp + 2 * px);
-                  const float l = rowp[xl];
-                  m = nmax(m, (iny && has_l) ? l : -INFINITY);
-                  m = nmax(m, iny ? cd.x : -INFINITY);
-                  m = nmax(m, iny ? cd.y : -INFINITY);
-                }
-                if (relu) m = m < 0.f ? 0.f : m;  // max and ReLU commute
-                if (ok) oplane[py * Wp + px] = m;
-              }
-            }
+          if (pool_pow2) {
+            readout_pool(i, wave);
             if (stamp) dbg_[121 + 2 * i] = __builtin_amdgcn_s_memtime();
             continue;
           }
