@@ -77,12 +77,12 @@ static int ensure_lds(Kern kern, int lds, bool* flags) {
   return BT_OK;
 }
 
-template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, int XMODE>
+template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, int XMODE, bool POOL = false>
 static int launch_fast(const FwdArgs& a, hipStream_t stream) {
   constexpr int lds = fused_lds_bytes<BN, BM, FLIP>();
   // narrow conv tiles: 8 producer waves (their accumulators leave room for 12 waves of <= 168 registers)
   constexpr int NPW = (!LINEAR && BM <= 128 && BN * BM <= (FLIP ? 64 * 128 : 128 * 128)) ? 8 : 4;  // Flipout 128x128 would spill at 168
-  auto fk = fused_fast_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, false, XMODE, NPW>;
+  auto fk = fused_fast_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, false, XMODE, NPW, POOL>;
   static bool fflags[64] = {};
   if (int rc = ensure_lds(fk, lds, fflags)) return rc;
   hipLaunchKernelGGL(fk, dim3((unsigned)a.total_blocks), dim3(256 + 64 * NPW), lds, stream, a);
@@ -96,7 +96,7 @@ static int launch_cfg(FwdArgs& a, hipStream_t stream) {
   a.n_tiles = (a.Cog + BN - 1) / BN;
   bool fast = false;
   if constexpr (!INJ) fast = fast_geometry<BM, LINEAR, FLIP>(a);  // injected draws are the parity/debug mode: always the general kernel
-  if (a.ep_pool && !(fast && TRANS && a.out_vec4 && !a.pixel_major && a.t_R == a.Ho && a.t_Wt == a.Wo))
+  if (a.ep_pool && !(fast && TRANS && !FLIP && BM >= 128 && a.x_rows && a.out_vec4 && !a.pixel_major && a.t_R == a.Ho && a.t_Wt == a.Wo))
     return set_error(BT_ERR_UNSUPPORTED, "fused max-pool: this launch's tiles do not hold whole output images");
   if (!fast) {  // general kernel: BM consecutive (b, ho, wo), or pixel-major
     if (a.pixel_major) {
@@ -117,7 +117,12 @@ static int launch_cfg(FwdArgs& a, hipStream_t stream) {
       // x staging mode (bt_fused_fast.h): row chunks need the wide spatial tiles, channel vectors the narrow ones
       constexpr bool has_rows = !LINEAR && !FLIP && BM >= 128, has_cvec = !LINEAR && BM <= 128;
       if constexpr (has_rows) {
-        if (a.x_rows) return launch_fast<BN, BM, CWN, FLIP, LINEAR, TRANS, 1>(a, stream);
+        if (a.x_rows) {
+          if constexpr (TRANS) {
+            if (a.ep_pool) return launch_fast<BN, BM, CWN, FLIP, LINEAR, TRANS, 1, true>(a, stream);
+          }
+          return launch_fast<BN, BM, CWN, FLIP, LINEAR, TRANS, 1>(a, stream);
+        }
       }
       if constexpr (has_cvec) {
         if (a.x_cvec && (a.HW == 1 || a.HW == 4)) return launch_fast<BN, BM, CWN, FLIP, LINEAR, TRANS, 2>(a, stream);
@@ -153,8 +158,8 @@ static int pick_tile(FwdArgs& a, hipStream_t stream) {
     // The fused max-pool needs tiles of whole images. When the size-driven choice has none (small batches pick narrow
     // tiles), take the narrowest tile that holds an image; launch_cfg launches nothing when it declines.
     if (rc == BT_ERR_UNSUPPORTED && a.ep_pool) {
-      if (a.HoWo <= 128) return launch_cfg<64, 128, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);
-      if constexpr (!FLIP) {
+      if constexpr (!FLIP) {  // (the pooled read-out lives in the row-chunk instantiations: Reparameterization, aligned x)
+        if (a.HoWo <= 128) return launch_cfg<64, 128, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);
         if (a.HoWo <= 256) return launch_cfg<64, 256, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
         if (a.HoWo <= 512) return launch_cfg<64, 512, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
       }

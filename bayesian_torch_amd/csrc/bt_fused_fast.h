@@ -27,8 +27,11 @@ __device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t& r, float
 // kernel's producer loop free of the other modes' registers and scalars.
 // NPW: producer waves (4: one per SIMD beside its consumer wave; 8: two per SIMD -- for the narrow tiles, whose weight
 // synthesis per MFMA is the largest and whose registers allow 12 waves per workgroup).
-template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, bool INJ, int XMODE = 0, int NPW = 4>
+// POOL: the output stage ends in MaxPool2d(3, 2, 1) (bt_epilogue.pool). Its own instantiation, of the row-chunk kernels only,
+// so that no other kernel carries the pooled read-out.
+template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, bool INJ, int XMODE = 0, int NPW = 4, bool POOL = false>
 __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArgs a) {
+  static_assert(!POOL || (XMODE == 1 && TRANS), "the pooled output stage lives in the row-chunk instantiations");
   constexpr int kProducers = 64 * NPW;  // (shadows the general kernel's constant)
   static_assert(NPW == 4 || (NPW == 8 && !LINEAR), "producer waves");
   static_assert(XMODE == 0 || !LINEAR, "x staging modes are for conv patches");
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
   // 16 -> 8): a wave = Wp pooled columns x 64/Wp staged planes (consecutive channels: their LDS rows are 4 banks apart),
   // walking the pooled rows. Window geometry is lane state decoded once; a window row is one 8-byte read (columns 2px,
   // 2px+1) plus the left neighbour. NaN wins, like torch's kernel. Shared by all waves where the quads read-out is.
-  const bool pool_pow2 = a.ep_pool && (a.ep_Wp & (a.ep_Wp - 1)) == 0 && a.ep_Wp >= 4 && a.ep_Wp <= 16;
+  const bool pool_pow2 = POOL && (a.ep_Wp & (a.ep_Wp - 1)) == 0 && a.ep_Wp >= 4 && a.ep_Wp <= 16;
   auto readout_pool = [&](int i, int wv) {
     constexpr int SROW = BM + 4, SROWS = 32 * CWN, NWV = kReadoutAll ? 4 + NPW : 4;
     const float* const stage = smem + 4 * BN;
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
         for (int i = 0; i < TN; ++i) {
           if (i > 0) __syncthreads();
           __syncthreads();
-          if (!a.ep_pool) readout_quads(i, tid);
+          if constexpr (!POOL) readout_quads(i, tid);
           else if (pool_pow2) readout_pool(i, wave);
         }
       } else {
@@ -812,7 +815,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
         }
         __syncthreads();
         if (stamp) dbg_[120 + 2 * i] = __builtin_amdgcn_s_memtime();
-        if (a.ep_pool) {
+        if constexpr (POOL) {
           // fused MaxPool2d(3, 2, 1) of whole staged images (tile column = (img * Ho + ho) * Wo + wo); NaN wins like torch's
           const int Hp = a.ep_Hp, Wp = a.ep_Wp, PP = Hp * Wp, per_row = t_NI * PP;
           if (pool_pow2) {

@@ -110,8 +110,9 @@ typedef struct bt_epilogue {
 
 /* Fused max-pool of the output stage's result -- the ResNet stem's conv -> (folded BN) -> ReLU -> MaxPool2d(3, 2, 1) as one
  * launch: out is [S][B][Co][Hp][Wp] with Hp = (Ho - 1) / 2 + 1, Wp = (Wo - 1) / 2 + 1, NaN-propagating like
- * torch.nn.functional.max_pool2d. No residual with it. The launch returns BT_ERR_UNSUPPORTED (nothing written) when its tile
- * does not hold whole output images (large feature maps) or the draws are injected: pool separately then. */
+ * torch.nn.functional.max_pool2d. No residual with it. The launch returns BT_ERR_UNSUPPORTED (nothing written) when it cannot
+ * fuse -- tiles that do not hold whole output images (large feature maps), Flipout, injected draws, input rows that are not
+ * 16-byte aligned (W % 4 != 0): pool separately then. */
 #define BT_POOL_NONE 0
 #define BT_POOL_MAX_3x3_S2_P1 1
 

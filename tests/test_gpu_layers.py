@@ -304,7 +304,8 @@ def test_fast_kernel_tile_geometries_vs_oracle(Ci, Co, k, st, pd, H, W, B, flip)
 @pytest.mark.parametrize("Ci,Co,k,st,pd,H,W,B,flip,fusable", [
     (3, 64, 7, 2, 3, 32, 32, 6, False, True),     # the CIFAR ResNet stem: two 16x16 images per 512-wide tile
     (3, 24, 7, 2, 3, 32, 32, 5, True, False),     # Flipout has no tile wider than 128 positions: 16x16 images -> separate pass
-    (6, 24, 3, 1, 1, 8, 8, 5, True, True),        # Flipout, 8x8 images, channel count that is not a tile multiple, ragged batch
+    (6, 24, 3, 1, 1, 8, 8, 5, True, False),       # Flipout stages x through registers (no row-chunk kernel): separate pass
+    (6, 24, 3, 1, 1, 8, 8, 5, False, True),       # 8x8 images, channel count that is not a tile multiple, ragged batch
     (8, 16, 3, 1, 1, 12, 8, 3, False, True),      # non-square, even sizes
     (4, 8, 3, 1, 1, 7, 8, 2, False, True),        # odd height: the last pooled row sees a 2-row window
     (3, 8, 7, 2, 3, 96, 96, 2, False, False),     # 48x48 outputs: row-band tiles -> separate pooling pass
