@@ -217,7 +217,7 @@ def main():
         nl = len(layers)
         ach = tot_fl / tot_ms / 1e9
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01q_pmc_traffic.json")   # measured offline: PMC passes cannot run inside this process
+        tfile = os.path.join(ROOT, "profiles", "r01r_pmc_traffic.json")   # measured offline: PMC passes cannot run inside this process
         if args.workload == "cfg3" and S == 32 and fused and world == 1 and os.path.exists(tfile):
             traffic = json.load(open(tfile))["traffic_bytes_per_launch"]
         roof = dict(bound="mfma", achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
