@@ -5,9 +5,13 @@
 //   * the stage shape (CC channels x NA active taps) is fixed, so the unit decode, the patch geometry and -- when all
 //     active taps fit one stage (kh*kw <= 9) -- each unit's tap and the K-row table are computed ONCE; larger kernels
 //     (7x7 stems) walk the taps in chunks of 9 over the same staged patch;
-//   * convolutions stage x as an LDS patch (each input pixel loaded once per stage, zero halo included), tiles are whole
-//     images or pixel-major; Linear stages its row-major tile with float4 loads.
-// Everything else (tiles that split images, planes that do not fit, injected draws, unaligned Linear) runs the general kernel.
+//   * convolutions stage x as an LDS patch (each input pixel loaded once per stage, zero halo included); tiles are
+//     t_NI images x t_R rows x t_Wt columns (whole images, row bands of large maps, or one pixel x BM images); the patch is
+//     filled by one of three staging modes, one per instantiation (XMODE below); Linear stages its row-major tile with
+//     float4 loads;
+//   * spatial outputs leave through an LDS-staged tile (whole 128-byte lines per store), optionally max-pooled (POOL).
+// Everything else (patches that do not fit LDS, injected draws, unaligned Linear, absent parameter packs) runs the general
+// kernel, which keeps the same order of accumulation: the two flavours agree bit for bit.
 #pragma once
 #include "bt_fused_fwd.h"
 
