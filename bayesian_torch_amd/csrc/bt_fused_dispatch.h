@@ -16,7 +16,7 @@ static bool fast_geometry(FwdArgs& a) {
   if (forced_off || !a.mu_pk || (((uintptr_t)a.mu_pk | (uintptr_t)a.sig_pk) & 15u) || a.T > kMaxTaps / 2 || a.w_elems >= (1ll << 29) ||
       a.x_elems >= (1ll << 29))
     return false;
-  constexpr long long XW = x_words<BM>();
+  constexpr long long XW = x_words<BM, FLIP>();
   const int dys = (a.KH - 1) * a.DH, dxs = (a.KW - 1) * a.DW;
   auto fits = [&](int NI, int R, int Wt) {
     const long long PHt = (long long)(R - 1) * (dys ? a.SH : 1) + dys + 1, PWt = (long long)(Wt - 1) * (dxs ? a.SW : 1) + dxs + 1;
@@ -130,7 +130,7 @@ static int launch_cfg(FwdArgs& a, hipStream_t stream) {
       return launch_fast<BN, BM, CWN, FLIP, LINEAR, TRANS, 0>(a, stream);
     }
   }
-  if constexpr (BM <= 256) {
+  if constexpr (BM <= (FLIP ? 128 : 256)) {
     auto kern = fused_fwd_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, INJ>;
     static bool gflags[64] = {};
     if (int rc = ensure_lds(kern, lds, gflags)) return rc;
@@ -189,6 +189,15 @@ static int pick_tile_by_size(FwdArgs& a, hipStream_t stream) {
     }
     if (Mdom >= 256 && a.Cog > 64 && tiles_for(a, 128, 256) >= kCUs) return launch_cfg<128, 256, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);
     if (Mdom >= 256 && tiles_for(a, 64, 256) >= kCUs) return launch_cfg<64, 256, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
+  }
+  if constexpr (FLIP && !LINEAR && !INJ) {
+    // Flipout's wide tile: 64x256, fast flavour only (two accumulator sets of 64 registers; x as a patch within the
+    // 128-column LDS budget). Halves the weight synthesis per MFMA on the large feature maps.
+    if (Mdom >= 256 && a.SH == 1 && a.SW == 1 && tiles_for(a, 64, 256) >= kCUs) {  // (strided convs: measured slower, their patches are 4x the outputs)
+      FwdArgs probe = a;
+      if (fast_geometry<256, false, true>(probe) && probe.t_NI * probe.t_R * probe.t_Wt >= 224)
+        return launch_cfg<64, 256, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);
+    }
   }
   if (a.Cog > 64 && tiles_for(a, 128, 128) >= kCUs) return launch_cfg<128, 128, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);
   return launch_cfg<64, 128, 2, FLIP, LINEAR, TRANS, INJ>(a, stream);

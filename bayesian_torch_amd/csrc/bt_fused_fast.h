@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
   constexpr int TN = WTN / 32, TM = WTM / 32;
   constexpr int WS = BN + 1, XS = BM + 1;
   constexpr int NW = FLIP ? 2 : 1;
-  constexpr int W_WORDS = kBK * WS, X_WORDS = x_words<BM>(), BUF_WORDS = NW * (W_WORDS + X_WORDS);
+  constexpr int W_WORDS = kBK * WS, X_WORDS = x_words<BM, FLIP>(), BUF_WORDS = NW * (W_WORDS + X_WORDS);
   static_assert(TN >= 1 && TM >= 1 && WTM * CWM == BM && WTN * CWN == BN, "tile shape");
   static_assert(!LINEAR || BM <= 256, "a Linear x tile is [k][BM]: only the patch form fits tiles wider than 256");
 
