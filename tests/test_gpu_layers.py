@@ -365,3 +365,35 @@ def test_fused_maxpool_propagates_nan():
     full, _ = F.fused_forward(x.cuda(), mu.cuda(), rho.cuda(), **kw)      # NaN in every channel of that pixel (0 * NaN)
     ref = torch.nn.functional.max_pool2d(full, 3, 2, 1)                   # the device op the unfused path runs: NaN wins
     assert torch.equal(torch.isnan(out), torch.isnan(ref)) and torch.isnan(ref).any() and not torch.isnan(ref).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flip", [True, False])
+def test_wide_tiles_at_chip_filling_sizes_vs_oracle(flip):
+    """The wide tiles are only chosen when a launch fills the chip (>= 256 workgroups), which the small cases above never do:
+    128 images of 8x8, 8 samples -> Flipout's 64x256 tile / the 64x512 row-chunk tile. Two of the samples are replayed through
+    the oracle (on-chip draws), ragged channel counts included."""
+    from oracle import bt_oracle as O
+    from bayesian_torch_amd import functional as F
+    Ci, Co, B, S = 12, 48, 128, 8
+    gen = torch.Generator().manual_seed(21)
+    mu = torch.randn(Co, Ci, 3, 3, generator=gen) * 0.1
+    rho = torch.randn(Co, Ci, 3, 3, generator=gen) * 0.1 - 3
+    mb, rb = torch.randn(Co, generator=gen) * 0.1, torch.randn(Co, generator=gen) * 0.1 - 3
+    x = torch.randn(B, Ci, 8, 8, generator=gen)
+    conv = dict(stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1)
+    seed, call, lid, s0 = 31, 4, 6, 2
+    dev = torch.device("cuda")
+    out, _ = F.fused_forward(x.cuda(), mu.cuda(), rho.cuda(), mb.cuda(), rb.cuda(), flip=flip, conv=conv, S=S, seed=seed, call=call,
+                             layer_id=lid, sample0=s0, packed=F.pack_params(mu.cuda(), rho.cuda()))
+    out = out.reshape(S, B, Co, 8, 8).cpu()
+    eps_w = F.rng_fill_normal(seed, call, lid, s0, 0, S, mu.shape, dev).cpu()
+    eps_b = F.rng_fill_normal(seed, call, lid, s0, 1, S, (Co,), dev).cpu()
+    for s in (0, S - 1):
+        if flip:
+            s_in = F.rng_fill_sign(seed, call, lid, s0, 2, S, x.shape, dev).cpu()
+            s_out = F.rng_fill_sign(seed, call, lid, s0, 3, S, (B, Co, 8, 8), dev).cpu()
+            ref = O.flipout_fwd_ref(x, mu, rho, eps_w[s], s_in[s], s_out[s], mb, rb, eps_b[s], conv)
+        else:
+            ref = O.reparam_fwd_ref(x, mu, rho, eps_w[s], mb, rb, eps_b[s], conv)
+        assert_close(out[s], ref, RTOL, ATOL, f"sample {s}")
