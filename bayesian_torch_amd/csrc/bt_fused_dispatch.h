@@ -193,7 +193,7 @@ static int pick_tile_by_size(FwdArgs& a, hipStream_t stream) {
   if constexpr (FLIP && !LINEAR && !INJ) {
     // Flipout's wide tile: 64x256, fast flavour only (two accumulator sets of 64 registers; x as a patch within the
     // 128-column LDS budget). Halves the weight synthesis per MFMA on the large feature maps.
-    if (Mdom >= 256 && a.SH == 1 && a.SW == 1 && tiles_for(a, 64, 256) >= kCUs) {  // (strided convs: measured slower, their patches are 4x the outputs)
+    if (Mdom >= 256 && ((a.SH == 1 && a.SW == 1) || a.T > 9) && tiles_for(a, 64, 256) >= kCUs) {  // (strided 3x3: measured slower; stems: faster)
       FwdArgs probe = a;
       if (fast_geometry<256, false, true>(probe) && probe.t_NI * probe.t_R * probe.t_Wt >= 224)
         return launch_cfg<64, 256, 1, FLIP, LINEAR, TRANS, INJ>(a, stream);

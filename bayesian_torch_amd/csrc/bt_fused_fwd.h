@@ -92,10 +92,11 @@ __host__ __device__ inline int row_chunks(int x_lo, int x_hi, int W, int* xa_out
 
 // Words of one LDS x buffer. Tiles up to 256 columns hold kBK im2col rows; the 512-wide tile (fast flavour only) stages x
 // as a patch and gets room for the 2-image 7x7/s2 stem patch of 32x32 inputs (4 x 2 x 37 x 37 words).
-// (Flipout keeps two x tiles per stage: its 256-wide tile -- fast flavour only, x as a patch -- gets the 128-column budget.)
+// (Flipout keeps two x tiles per stage: its 256-wide tile -- fast flavour only, x as a patch -- gets a 160-column budget:
+// room for the 37x37 patch of one 7x7/s2 stem image.)
 template <int BM, bool FLIP = false>
 constexpr int x_words() {
-  return kBK * ((FLIP && BM > 128 ? 128 : BM <= 256 ? BM : 320) + 1);
+  return kBK * ((FLIP && BM > 128 ? 160 : BM <= 256 ? BM : 320) + 1);
 }
 
 template <int BN, int BM, bool FLIP>
