@@ -81,7 +81,7 @@ template <int BN, int BM, int CWN, bool FLIP, bool LINEAR, bool TRANS, int XMODE
 static int launch_fast(const FwdArgs& a, hipStream_t stream) {
   constexpr int lds = fused_lds_bytes<BN, BM, FLIP>();
   // narrow conv tiles: 8 producer waves (their accumulators leave room for 12 waves of <= 168 registers)
-  constexpr int NPW = (!LINEAR && BM <= 128 && BN * BM <= (FLIP ? 64 * 128 : 128 * 128)) ? 8 : 4;  // Flipout 128x128 would spill at 168
+  constexpr int NPW = (!LINEAR && BM <= 128 && BN * BM <= 128 * 128) ? 8 : 4;
   auto fk = fused_fast_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, false, XMODE, NPW, POOL>;
   static bool fflags[64] = {};
   if (int rc = ensure_lds(fk, lds, fflags)) return rc;
