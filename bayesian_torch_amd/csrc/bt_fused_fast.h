@@ -468,10 +468,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
               const uint32_t off = (chan && p_off[i] != (int)kOOB) ? (uint32_t)(p_off[i] + cbyte) : kOOB;
               const float4 x4 = ldf4(r_x, off);
               xv[4 * i] = x4.x, xv[4 * i + 1] = x4.y, xv[4 * i + 2] = x4.z, xv[4 * i + 3] = x4.w;
-              if constexpr (FLIP) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xo[4 * i + j] = (off >> 2) + j;
-              }
+
             }
           }
         }
@@ -484,7 +481,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
             for (int c = 0; c < CCs; ++c) {
               const uint32_t off = (c0 + c < Cig) ? (uint32_t)(p_off[i] + c0HWb + c * HWb) : kOOB;  // channel test is uniform
               xv[i * CCs + c] = ldf(r_x, off);
-              if constexpr (FLIP) xo[i * CCs + c] = off >> 2;
+
             }
           }
         }
@@ -533,18 +530,19 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
 #pragma unroll
           for (int i = 0; i < (XMODE == 2 ? PPOS : 1); ++i) {
             if (kProducers * i < nvec && cv_l[i] >= 0) {
+              const uint32_t xo0 = (uint32_t)(p_off[i] + c0 * (cvecA ? 4 : 16)) >> 2;  // sign index of the vector's first element
               if (cvecA) {  // 4 channels of one image: 4 planes
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                   Xt0[cv_l[i] + j * PST] = xv[4 * i + j];
-                  if (FLIP) Xt1[cv_l[i] + j * PST] = __fmul_rn(xv[4 * i + j], hash_sign(skey_in, xo[4 * i + j]));
+                  if (FLIP) Xt1[cv_l[i] + j * PST] = __fmul_rn(xv[4 * i + j], hash_sign(skey_in, xo0 + j));
                 }
               } else {  // the 2x2 plane of one channel: 4 consecutive patch words
                 *reinterpret_cast<float4*>(Xt0 + cv_l[i]) = make_float4(xv[4 * i], xv[4 * i + 1], xv[4 * i + 2], xv[4 * i + 3]);
                 if (FLIP)
                   *reinterpret_cast<float4*>(Xt1 + cv_l[i]) =
-                      make_float4(__fmul_rn(xv[4 * i], hash_sign(skey_in, xo[4 * i])), __fmul_rn(xv[4 * i + 1], hash_sign(skey_in, xo[4 * i + 1])),
-                                  __fmul_rn(xv[4 * i + 2], hash_sign(skey_in, xo[4 * i + 2])), __fmul_rn(xv[4 * i + 3], hash_sign(skey_in, xo[4 * i + 3])));
+                      make_float4(__fmul_rn(xv[4 * i], hash_sign(skey_in, xo0)), __fmul_rn(xv[4 * i + 1], hash_sign(skey_in, xo0 + 1)),
+                                  __fmul_rn(xv[4 * i + 2], hash_sign(skey_in, xo0 + 2)), __fmul_rn(xv[4 * i + 3], hash_sign(skey_in, xo0 + 3)));
               }
             }
           }
@@ -558,7 +556,9 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
             for (int c = 0; c < CCs; ++c) {
               const float v = xv[i * CCs + c];
               Xt0[c * PST + pos] = v;
-              if (FLIP) Xt1[c * PST + pos] = __fmul_rn(v, hash_sign(skey_in, xo[i * CCs + c]));
+              // (the sign index = the element's index in the sample's x, rebuilt from the offsets instead of carried in registers;
+              //  halo cells hold 0 and take whatever sign a wild index hashes to)
+              if (FLIP) Xt1[c * PST + pos] = __fmul_rn(v, hash_sign(skey_in, (uint32_t)(p_off[i] + 4 * (c0 + c) * a.HW) >> 2));
             }
           }
         }
