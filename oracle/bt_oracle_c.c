@@ -11,6 +11,7 @@
  * Reference lines followed (under /root/reference/bayesian_torch/):
  *   sampling        layers/variational_layers/linear_variational.py:163-166, conv_variational.py:366-369
  *   KL normal       layers/base_variational_layer.py:70-72
+ *   KL laplace      layers/base_variational_layer.py:74-97 (prior location 0 and scale 1 hard-coded there)
  *   conv / linear   F.conv2d / F.linear call sites: conv_variational.py:384, linear_variational.py:181
  *   flipout         layers/flipout_layers/conv_flipout.py:376-417, linear_flipout.py:149-174
  */
@@ -28,6 +29,20 @@ double bto_kl_normal(const float *mu, const float *rho, const float *pmu, const 
     const float d = mu[i] - pmu[i];
     const float t = logf(psig[i]) - logf(sq) + (sq * sq + d * d) / (2.0f * (psig[i] * psig[i])) - 0.5f;
     acc += (double)t;
+  }
+  return acc / (double)n;
+}
+
+/* mean_i( log 2 - 0.5 log(2 pi sq^2) - 0.5 + E|w| ),  E|w| = sq sqrt(2/pi) exp(-mu^2 / (2 sq^2)) + mu (1 - 2 Phi(-mu/sq)),
+ * Phi(-z) = erfc(z / sqrt 2) / 2  =>  1 - 2 Phi(-z) = erf(z / sqrt 2). Per element in fp64 (an independent check of the
+ * fp32 op chain), mean in fp64. */
+double bto_kl_laplace(const float *mu, const float *rho, int64_t n) {
+  const double two_over_pi = 0.63661977236758134308, two_pi = 6.28318530717958647692;
+  double acc = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    const double sq = (double)softplus_f(rho[i]), m = (double)mu[i];
+    const double e_abs = sq * sqrt(two_over_pi) * exp(-m * m / (2.0 * sq * sq)) + m * erf(m / (sq * 1.41421356237309504880));
+    acc += log(2.0) - 0.5 * log(two_pi * sq * sq) - 0.5 + e_abs;
   }
   return acc / (double)n;
 }

@@ -20,6 +20,8 @@ def lib():
         _lib = C.CDLL(_SO)
         _lib.bto_kl_normal.restype = C.c_double
         _lib.bto_kl_normal.argtypes = [_fp] * 4 + [C.c_int64]
+        _lib.bto_kl_laplace.restype = C.c_double
+        _lib.bto_kl_laplace.argtypes = [_fp] * 2 + [C.c_int64]
         _lib.bto_sample.argtypes = [_fp] * 3 + [C.c_int64, _fp, _fp]
         _lib.bto_conv2d.argtypes = [_fp] * 4 + [C.c_int] * 14
         _lib.bto_linear.argtypes = [_fp] * 4 + [C.c_int] * 3
@@ -39,6 +41,11 @@ def _p(a):
 def kl_normal(mu, rho, pmu, psig):
     m, r, p, s = _a(mu), _a(rho), _a(pmu), _a(psig)
     return float(lib().bto_kl_normal(_p(m), _p(r), _p(p), _p(s), m.size))
+
+
+def kl_laplace(mu, rho):
+    m, r = _a(mu), _a(rho)
+    return float(lib().bto_kl_laplace(_p(m), _p(r), m.size))
 
 
 def kl_layer(mu_w, rho_w, pmu_w, psig_w, mu_b=None, rho_b=None, pmu_b=None, psig_b=None):

@@ -45,9 +45,12 @@ def layer_tensors(g):
     conv = None
     c = m["ctor"]
     if "Conv" in m["cls"]:
-        pair = lambda v: tuple(v) if isinstance(v, (list, tuple)) else (v, v)
-        conv = dict(stride=pair(c.get("stride", 1)), padding=pair(c.get("padding", 0)),
-                    dilation=pair(c.get("dilation", 1)), groups=c.get("groups", 1))
+        nd = g["mu_w"].dim() - 2
+        tup = lambda v: tuple(v) if isinstance(v, (list, tuple)) else (v,) * nd
+        conv = dict(stride=tup(c.get("stride", 1)), padding=tup(c.get("padding", 0)),
+                    dilation=tup(c.get("dilation", 1)), groups=c.get("groups", 1))
+        if "Transpose" in m["cls"]:
+            conv.update(transposed=True, output_padding=tup(c.get("output_padding", 0)))
     t["conv"] = conv
     return t
 

@@ -8,6 +8,7 @@ from oracle import bt_oracle as O
 from bayesian_torch_amd.harness import resnet as H
 
 LAYER_FIX = golden_names("linear_") + golden_names("conv2d_")
+FAMILY_FIX = golden_names("conv1d_") + golden_names("conv3d_") + golden_names("convt")   # section 8(f) rank 4: the rest of the layer family
 
 
 @pytest.mark.parametrize("name", LAYER_FIX)
@@ -31,6 +32,8 @@ def _build(meta):
     torch.manual_seed(meta["seed"])
     if len(meta["x_shape"]) == 2:
         net = H.mlp((3072, 512, 10))
+    elif "r50" in meta["_name"]:
+        net = H.resnet50(1000, width=64)
     else:
         net = H.resnet18(10, width=8 if "w8" in meta["_name"] else 64)
     O.ref_dnn_to_bnn(net, meta["btype"])
@@ -62,9 +65,10 @@ def test_model_replay_from_seed(name):
     assert_close(p_sum / meta["S"], g["mean_prob"], rtol=1e-5, atol_scale=1e-6, what=name + ".mean_prob")
 
 
-@pytest.mark.parametrize("name", ["model_r18_reparam", "model_r18_flipout"])
+@pytest.mark.parametrize("name", ["model_r18_reparam", "model_r18_flipout", "model_r50_reparam"])
 def test_full_width_r18_replay(name):
-    """cfg3 / cfg4 of BASELINE.json at full width: only (seed, logits, kl, checksums) are stored."""
+    """cfg3 / cfg4 / cfg5's model of BASELINE.json at full width (cfg5: ResNet50 on 3x224x224, batch 2): only
+    (seed, logits, kl, checksums) are stored."""
     g = load_golden(name)
     meta = dict(g["meta"], _name=name)
     torch.set_num_threads(8)
@@ -110,3 +114,55 @@ def test_conv1d_goldens_through_oracle(name):
     else:
         out = O.reparam_fwd_ref(x4, w4(g["mu_w"]), w4(g["rho_w"]), w4(g["eps_w"]), g["mu_b"], g["rho_b"], g["eps_b"], conv)
     assert_close(out.squeeze(2), g["out"], rtol=1e-5, atol_scale=1e-6, what=name)
+
+
+@pytest.mark.parametrize("name", FAMILY_FIX)
+def test_layer_family_forward_and_kl(name):
+    """Conv1d / Conv3d / ConvTranspose{1,2,3}d fixtures (both flavours) through the oracle's N-d contraction."""
+    g = layer_tensors(load_golden(name))
+    if "flipout" in name:
+        out = O.flipout_fwd_ref(g["x"], g["mu_w"], g["rho_w"], g["eps_w"], g["sign_in"], g["sign_out"],
+                                g["mu_b"], g["rho_b"], g["eps_b"], g["conv"])
+    else:
+        out = O.reparam_fwd_ref(g["x"], g["mu_w"], g["rho_w"], g["eps_w"], g["mu_b"], g["rho_b"], g["eps_b"], g["conv"])
+    assert_close(out, g["out"], rtol=1e-5, atol_scale=1e-6, what=name + ".out")
+    kl = O.kl_layer_ref(g["mu_w"], g["rho_w"], g["prior_mu_w"], g["prior_sigma_w"], g["mu_b"], g["rho_b"], g["prior_mu_b"], g["prior_sigma_b"])
+    assert_close(kl, g["kl"], rtol=1e-6, atol_scale=0, what=name + ".kl")
+
+
+@pytest.mark.parametrize("name", ["lstm_reparam_7x5", "lstm_flipout_7x5"])
+def test_lstm_goldens_through_oracle(name):
+    g = load_golden(name)
+    flip = "flipout" in name
+    Hh = g["meta"]["out_features"]
+
+    def step(nm):
+        def f(t, v):
+            a = [g[f"{nm}_{k}"] for k in ("mu_w", "rho_w")] + [g[f"{nm}_eps_w"][t]]
+            b = [g[f"{nm}_mu_b"], g[f"{nm}_rho_b"], g[f"{nm}_eps_b"][t]]
+            if flip:
+                return O.flipout_fwd_ref(v, *a, g[f"{nm}_sign_in"][t], g[f"{nm}_sign_out"][t], *b)
+            return O.reparam_fwd_ref(v, *a, *b)
+        return f
+    hs, cs = O.lstm_ref(g["x"], step("ih"), step("hh"), Hh)
+    assert_close(hs, g["hidden_seq"], rtol=1e-5, atol_scale=1e-6, what=name + ".hidden_seq")
+    assert_close(cs, g["c_ts"], rtol=1e-5, atol_scale=1e-6, what=name + ".c_ts")
+    one = lambda nm: O.kl_layer_ref(g[nm + "_mu_w"], g[nm + "_rho_w"], torch.zeros_like(g[nm + "_mu_w"]), torch.ones_like(g[nm + "_mu_w"]),
+                                    g[nm + "_mu_b"], g[nm + "_rho_b"], torch.zeros_like(g[nm + "_mu_b"]), torch.ones_like(g[nm + "_mu_b"]))
+    assert_close(one("ih") + one("hh"), g["kl_loss"], rtol=1e-6, atol_scale=0, what=name + ".kl_loss")
+    T = g["meta"]["x_shape"][1]
+    assert_close(T * (one("ih") + one("hh")), g["kl"], rtol=1e-5, atol_scale=0, what=name + ".kl (summed over the steps)")
+
+
+def test_laplace_kl_goldens():
+    """prior_type='laplace' (base_variational_layer.py:74-97), oracle and plain-C restatement."""
+    from oracle import c_oracle as CO
+    g = load_golden("kl_laplace")
+    for tag in g["meta"]["cases"]:
+        mu, rho = g[tag + "_mu"], g[tag + "_rho"]
+        assert_close(O.kl_laplace_ref(mu, O.softplus_ref(rho)), g[tag + "_kl"], rtol=1e-6, atol_scale=0, what="laplace " + tag)
+        c = CO.kl_laplace(mu, rho)
+        assert abs(c - float(g[tag + "_kl"])) <= 3e-6 * abs(float(g[tag + "_kl"])), (tag, c, float(g[tag + "_kl"]))
+    for nm in ("lin", "conv"):
+        kl = O.kl_laplace_ref(g[nm + "_mu_w"], O.softplus_ref(g[nm + "_rho_w"])) + O.kl_laplace_ref(g[nm + "_mu_b"], O.softplus_ref(g[nm + "_rho_b"]))
+        assert_close(kl, g[nm + "_kl"], rtol=1e-6, atol_scale=0, what="laplace layer " + nm)

@@ -16,10 +16,14 @@ SURVEY.md Appendix B.
     sign tensors are recovered by replaying the seeded draws in the layer's
     draw order and asserting the replayed eps equals the buffer.
 
-Usage:  python tools/make_goldens.py      (writes tests/golden/)
-(conv1d_*.npz, lstm_reparam_7x5.npz and uncertainty.npz were produced by the same recipe in an interactive session:
-Conv1d{Reparameterization,Flipout}(6, 10, 3, stride=2, padding=1) on x[3,6,17] with seeds 11/12/13 and return_kl=False;
-LSTMReparameterization(7, 5) on X[3,4,7] with seeds 21/22/23, per-step eps recovered by replaying the seeded draws.)
+  * Classes whose kl_div call lacks prior_type in this fork (every layer except Linear/Conv2d
+    Reparameterization) run with return_kl=False; LSTM wrappers, which always unpack (out, kl) from their
+    inner Linear layers, get the documented 4-argument normal KL bound on those inner layers (shim (ii)).
+  * 'laplace' fixtures call kl_div(..., 'laplace') (base_variational_layer.py:74-97; it hard-codes
+    b_p = 1, mu_p = 0 and prints -- stdout is swallowed here).
+
+Usage:  python tools/make_goldens.py [section ...]     (writes tests/golden/; sections: layers conv1d lstm
+        models r50 laplace misc transpose conv3d; no argument = all)
 """
 import json
 import os
@@ -71,7 +75,8 @@ def layer_case(name, cls_name, ctor, x_shape, seeds=(11, 12, 13), random_priors=
     cls = getattr(RL, cls_name)
     torch.manual_seed(seed_p)
     kw = dict(ctor)
-    if not flip:
+    has_pt = cls_name in ("LinearReparameterization", "Conv2dReparameterization")   # the only two ctors with prior_type in this fork
+    if has_pt:
         kw["prior_type"] = "normal"
     layer = cls(**kw)
     wn = "kernel" if "Conv" in cls_name else "weight"
@@ -87,7 +92,7 @@ def layer_case(name, cls_name, ctor, x_shape, seeds=(11, 12, 13), random_priors=
     mu_w, rho_w = getattr(layer, "mu_" + wn), getattr(layer, "rho_" + wn)
     with torch.no_grad():
         torch.manual_seed(seed_f)
-        if flip:
+        if not has_pt:
             out = layer(x, return_kl=False)
         else:
             out, kl_fwd = layer(x)
@@ -109,13 +114,19 @@ def layer_case(name, cls_name, ctor, x_shape, seeds=(11, 12, 13), random_priors=
                 sign_out = torch.empty_like(out).uniform_(-1, 1).sign()
             assert torch.equal(e_w, eps_w), "replayed eps != buffer"
             assert e_b is None or torch.equal(e_b, eps_b)
-        kl_w = layer.kl_div(mu_w, sp(rho_w), layer.prior_weight_mu, layer.prior_weight_sigma, "normal")
+        pm_w, ps_w = layer.prior_weight_mu, layer.prior_weight_sigma
+        if ps_w.shape != mu_w.shape or pm_w.shape != mu_w.shape:
+            # ConvTranspose*Flipout register prior_weight_sigma as [Co][Ci/g].. while the kernel is [Ci][Co/g].. (conv_flipout.py:
+            # 904-908): their own KL cannot broadcast. The buffers are constant fills, so the KL of record uses the same constants
+            # in the kernel's shape (what every other class does).
+            pm_w, ps_w = torch.full_like(mu_w, float(layer.prior_mean)), torch.full_like(mu_w, float(layer.prior_variance))
+        kl_w = layer.kl_div(mu_w, sp(rho_w), pm_w, ps_w, "normal")
         kl_b = None
         kl = kl_w.clone()
         if layer.mu_bias is not None:
             kl_b = layer.kl_div(layer.mu_bias, sp(layer.rho_bias), layer.prior_bias_mu, layer.prior_bias_sigma, "normal")
             kl = kl_w + kl_b
-        if not flip:
+        if has_pt:
             assert torch.equal(kl, kl_fwd), (kl, kl_fwd)
             assert torch.equal(kl, layer.kl_loss())
     meta = dict(cls=cls_name, ctor=ctor, x_shape=list(x_shape), seeds=list(seeds), torch=torch.__version__,
@@ -145,6 +156,96 @@ CONV_CASES = [
     ("c6x10k3x2", dict(in_channels=6, out_channels=10, kernel_size=(3, 2), stride=(2, 1), padding=(1, 0)), (2, 6, 7, 6), True),
     ("c64x64k3hw1", dict(in_channels=64, out_channels=64, kernel_size=3, padding=1, bias=False), (4, 64, 1, 1), False),
 ]
+
+
+
+def lstm_case(name, cls_name, in_f, out_f, x_shape, seeds=(21, 22, 23)):
+    """LSTM{Reparameterization,Flipout} (rnn_variational.py:45-153, rnn_flipout.py:46-154): two Linear layers per
+    time step. Per-step draws are recovered by replaying the seeded generator in the layers' draw order."""
+    seed_p, seed_x, seed_f = seeds
+    flip = cls_name.endswith("Flipout")
+    torch.manual_seed(seed_p)
+    lstm = getattr(RL, cls_name)(in_f, out_f)
+    if flip:   # shim (ii): LinearFlipout's own kl_div call lacks prior_type in this fork
+        for lin in (lstm.ih, lstm.hh):
+            lin.kl_div = (lambda l: (lambda mq, sq, mp, sp_: type(l).kl_div(l, mq, sq, mp, sp_, "normal")))(lin)
+    torch.manual_seed(seed_x)
+    X = torch.randn(*x_shape)
+    B, T = x_shape[0], x_shape[1]
+    with torch.no_grad():
+        torch.manual_seed(seed_f)
+        hs, (_, cs), kl = lstm(X)
+        torch.manual_seed(seed_f)
+        d = {f"{nm}_{k}": [] for nm in ("ih", "hh") for k in ("eps_w", "eps_b", "sign_in", "sign_out")}
+        for t in range(T):
+            for nm, fin in (("ih", in_f), ("hh", out_f)):
+                lin = getattr(lstm, nm)
+                d[nm + "_eps_w"].append(torch.empty_like(lin.eps_weight).normal_())
+                d[nm + "_eps_b"].append(torch.empty_like(lin.eps_bias).normal_())
+                if flip:    # linear_flipout.py:149-170: eps_w, eps_b, s_in, s_out
+                    d[nm + "_sign_in"].append(torch.empty(B, fin).uniform_(-1, 1).sign())
+                    d[nm + "_sign_out"].append(torch.empty(B, 4 * out_f).uniform_(-1, 1).sign())
+        for nm in ("ih", "hh"):
+            assert torch.equal(d[nm + "_eps_w"][-1], getattr(lstm, nm).eps_weight), "replayed eps != buffer"
+        if flip:
+            kl_loss = sum(l.kl_div(l.mu_weight, sp(l.rho_weight), l.prior_weight_mu, l.prior_weight_sigma)
+                          + l.kl_div(l.mu_bias, sp(l.rho_bias), l.prior_bias_mu, l.prior_bias_sigma) for l in (lstm.ih, lstm.hh))
+        else:
+            kl_loss = lstm.kl_loss()
+    arrs = dict(x=npf(X), hidden_seq=npf(hs), c_ts=npf(cs), kl=npf(kl), kl_loss=npf(kl_loss))
+    for nm in ("ih", "hh"):
+        lin = getattr(lstm, nm)
+        arrs.update({nm + "_mu_w": npf(lin.mu_weight), nm + "_rho_w": npf(lin.rho_weight), nm + "_mu_b": npf(lin.mu_bias), nm + "_rho_b": npf(lin.rho_bias)})
+    for k, v in d.items():
+        if v:
+            arrs[k] = npf(torch.stack(v))
+    save(name, dict(cls=cls_name, in_features=in_f, out_features=out_f, x_shape=list(x_shape), seeds=list(seeds), torch=torch.__version__), **arrs)
+
+
+def laplace_cases():
+    """kl_div(..., 'laplace') known answers (base_variational_layer.py:74-97). The branch ignores the prior tensors it is
+    handed (b_p = 1, mu_p = 0 are hard-coded) and prints; also through LinearReparameterization / Conv2dReparameterization
+    constructed with prior_type='laplace' (forward kl == kl_loss())."""
+    import contextlib
+    import io
+    g = torch.Generator().manual_seed(41)
+    base = RL.LinearReparameterization(2, 2)
+    arrs, meta = {}, dict(cases=[])
+    for tag, n, mu_s, rho_m in (("a", 4099, 0.1, -3.0), ("b", 513, 1.5, 0.5), ("c", 64, 0.0, -8.0)):
+        mu = torch.randn(n, generator=g) * mu_s
+        if tag == "c":
+            mu[:8] = 0.0          # exactly-zero means: the folded-normal mean reduces to sigma*sqrt(2/pi)
+        rho = torch.randn(n, generator=g) * 0.3 + rho_m
+        pm, ps = torch.randn(n, generator=g), torch.rand(n, generator=g) + 0.5      # ignored by the branch
+        with contextlib.redirect_stdout(io.StringIO()):
+            kl = base.kl_div(mu, sp(rho), pm, ps, "laplace")
+        arrs.update({f"{tag}_mu": npf(mu), f"{tag}_rho": npf(rho), f"{tag}_pmu": npf(pm), f"{tag}_psig": npf(ps), f"{tag}_kl": npf(kl)})
+        meta["cases"].append(tag)
+    with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+        torch.manual_seed(42)
+        lin = RL.LinearReparameterization(37, 11, prior_type="laplace")
+        out, kl_f = lin(torch.randn(3, 37))
+        assert torch.equal(kl_f, lin.kl_loss())
+        arrs.update(lin_mu_w=npf(lin.mu_weight), lin_rho_w=npf(lin.rho_weight), lin_mu_b=npf(lin.mu_bias), lin_rho_b=npf(lin.rho_bias), lin_kl=npf(kl_f))
+        conv = RL.Conv2dReparameterization(5, 6, 3, prior_type="laplace")
+        out, kl_c = conv(torch.randn(2, 5, 6, 6))
+        assert torch.equal(kl_c, conv.kl_loss())
+        arrs.update(conv_mu_w=npf(conv.mu_kernel), conv_rho_w=npf(conv.rho_kernel), conv_mu_b=npf(conv.mu_bias), conv_rho_b=npf(conv.rho_bias), conv_kl=npf(kl_c))
+    save("kl_laplace", meta, **arrs)
+
+
+CONV1D_CASES = [("c6x10k3s2", dict(in_channels=6, out_channels=10, kernel_size=3, stride=2, padding=1), (3, 6, 17))]
+CONVT2D_CASES = [
+    ("c6x4k3s2", dict(in_channels=6, out_channels=4, kernel_size=3, stride=2, padding=1, output_padding=1), (2, 6, 5, 5)),
+    ("c8x6k4s2g2", dict(in_channels=8, out_channels=6, kernel_size=4, stride=2, padding=1, groups=2), (2, 8, 4, 6)),
+    ("c5x7k3d2nb", dict(in_channels=5, out_channels=7, kernel_size=(3, 2), stride=1, padding=(2, 0), dilation=(2, 1), bias=False), (3, 5, 6, 5)),
+]
+CONVT1D_CASES = [("c6x4k4s2", dict(in_channels=6, out_channels=4, kernel_size=4, stride=2, padding=1), (3, 6, 9))]
+CONV3D_CASES = [
+    ("c3x5k3", dict(in_channels=3, out_channels=5, kernel_size=3, padding=1), (2, 3, 4, 6, 6)),
+    ("c4x6k3s2g2", dict(in_channels=4, out_channels=6, kernel_size=(3, 3, 2), stride=(2, 2, 1), padding=(1, 1, 0), groups=2), (2, 4, 5, 7, 4)),
+]
+CONVT3D_CASES = [("c4x3k3s2", dict(in_channels=4, out_channels=3, kernel_size=3, stride=2, padding=1, output_padding=1), (2, 4, 3, 3, 3))]
 
 
 def model_case(name, build, x_shape, btype, S, seed, store_full):
@@ -195,22 +296,57 @@ def model_case(name, build, x_shape, btype, S, seed, store_full):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    only = sys.argv[1] if len(sys.argv) > 1 else ""
-    print("layer fixtures")
-    for tag, ctor, xs, rp in LINEAR_CASES:
-        layer_case("linear_reparam_" + tag, "LinearReparameterization", ctor, xs, random_priors=rp)
-        layer_case("linear_flipout_" + tag, "LinearFlipout", ctor, xs, random_priors=rp)
-    for tag, ctor, xs, rp in CONV_CASES:
-        layer_case("conv2d_reparam_" + tag, "Conv2dReparameterization", ctor, xs, random_priors=rp)
-        layer_case("conv2d_flipout_" + tag, "Conv2dFlipout", ctor, xs, random_priors=rp)
+    want = set(sys.argv[1:])
+    sec = lambda n: not want or n in want
+    if sec("layers"):
+        print("layer fixtures")
+        for tag, ctor, xs, rp in LINEAR_CASES:
+            layer_case("linear_reparam_" + tag, "LinearReparameterization", ctor, xs, random_priors=rp)
+            layer_case("linear_flipout_" + tag, "LinearFlipout", ctor, xs, random_priors=rp)
+        for tag, ctor, xs, rp in CONV_CASES:
+            layer_case("conv2d_reparam_" + tag, "Conv2dReparameterization", ctor, xs, random_priors=rp)
+            layer_case("conv2d_flipout_" + tag, "Conv2dFlipout", ctor, xs, random_priors=rp)
+    if sec("conv1d"):
+        for tag, ctor, xs in CONV1D_CASES:
+            layer_case("conv1d_reparam_" + tag, "Conv1dReparameterization", ctor, xs)
+            layer_case("conv1d_flipout_" + tag, "Conv1dFlipout", ctor, xs)
+    if sec("transpose"):
+        for tag, ctor, xs in CONVT2D_CASES:
+            layer_case("convt2d_reparam_" + tag, "ConvTranspose2dReparameterization", ctor, xs)
+            layer_case("convt2d_flipout_" + tag, "ConvTranspose2dFlipout", ctor, xs)
+        for tag, ctor, xs in CONVT1D_CASES:
+            layer_case("convt1d_reparam_" + tag, "ConvTranspose1dReparameterization", ctor, xs)
+            layer_case("convt1d_flipout_" + tag, "ConvTranspose1dFlipout", ctor, xs)
+        for tag, ctor, xs in CONVT3D_CASES:
+            layer_case("convt3d_reparam_" + tag, "ConvTranspose3dReparameterization", ctor, xs)
+            # ConvTranspose3dFlipout.forward with a bias and return_kl=False raises UnboundLocalError in this fork
+            # (conv_flipout.py:1192 adds the bias KL unconditionally): its fixture is bias-free
+            layer_case("convt3d_flipout_" + tag + "nb", "ConvTranspose3dFlipout", dict(ctor, bias=False), xs)
+    if sec("conv3d"):
+        for tag, ctor, xs in CONV3D_CASES:
+            # Conv3dReparameterization takes its prior / posterior arguments positionally, without defaults (conv_variational.py:651-663)
+            layer_case("conv3d_reparam_" + tag, "Conv3dReparameterization",
+                       dict(ctor, prior_mean=0, prior_variance=1, posterior_mu_init=0, posterior_rho_init=-3.0), xs)
+            layer_case("conv3d_flipout_" + tag, "Conv3dFlipout", ctor, xs)
+    if sec("lstm"):
+        lstm_case("lstm_reparam_7x5", "LSTMReparameterization", 7, 5, (3, 4, 7))
+        lstm_case("lstm_flipout_7x5", "LSTMFlipout", 7, 5, (3, 4, 7))
+    if sec("laplace"):
+        laplace_cases()
 
-    print("model fixtures")
-    model_case("model_r18w8_reparam", lambda: H.resnet18(10, width=8), (4, 3, 32, 32), "Reparameterization", 3, 5, True)
-    model_case("model_r18w8_flipout", lambda: H.resnet18(10, width=8), (4, 3, 32, 32), "Flipout", 3, 5, True)
-    model_case("model_mlp_reparam", lambda: H.mlp((3072, 512, 10)), (8, 3072), "Reparameterization", 2, 6, False)
-    # full width, cfg3/cfg4 of BASELINE.json: only (seed, logits, kl, checksums) are stored
-    model_case("model_r18_reparam", lambda: H.resnet18(10, width=64), (128, 3, 32, 32), "Reparameterization", 1, 3, False)
-    model_case("model_r18_flipout", lambda: H.resnet18(10, width=64), (128, 3, 32, 32), "Flipout", 1, 3, False)
+    if sec("models"):
+        print("model fixtures")
+        model_case("model_r18w8_reparam", lambda: H.resnet18(10, width=8), (4, 3, 32, 32), "Reparameterization", 3, 5, True)
+        model_case("model_r18w8_flipout", lambda: H.resnet18(10, width=8), (4, 3, 32, 32), "Flipout", 3, 5, True)
+        model_case("model_mlp_reparam", lambda: H.mlp((3072, 512, 10)), (8, 3072), "Reparameterization", 2, 6, False)
+        # full width, cfg3/cfg4 of BASELINE.json: only (seed, logits, kl, checksums) are stored
+        model_case("model_r18_reparam", lambda: H.resnet18(10, width=64), (128, 3, 32, 32), "Reparameterization", 1, 3, False)
+        model_case("model_r18_flipout", lambda: H.resnet18(10, width=64), (128, 3, 32, 32), "Flipout", 1, 3, False)
+    if sec("r50"):
+        # cfg5's model at full width and full image size (ResNet50, 3x224x224); batch 2, one sample: seeds + logits + checksums
+        model_case("model_r50_reparam", lambda: H.resnet50(1000, width=64), (2, 3, 224, 224), "Reparameterization", 1, 7, False)
+    if not sec("misc"):
+        return
 
     print("get_rho known answers (utils/util.py:63-69)")
     g = torch.Generator().manual_seed(21)
