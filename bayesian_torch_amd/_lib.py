@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libbtorch_hip.so")
 WORKSPACE_BYTES = 65536
 KL_MAX_SEGMENTS = 64
 KL_RHO_IS_SIGMA = 1
+KL_PRIOR_LAPLACE = 2
+PRIOR_NORMAL, PRIOR_LAPLACE = 0, 1
 
 _f32p = C.POINTER(C.c_float)
 _vp = C.c_void_p
@@ -25,7 +27,8 @@ class bt_rng(C.Structure):
 
 
 class bt_params(C.Structure):
-    _fields_ = [(n, _vp) for n in ("mu_w", "rho_w", "mu_b", "rho_b", "prior_mu_w", "prior_sigma_w", "prior_mu_b", "prior_sigma_b", "mu_packed", "sigma_packed")]
+    _fields_ = [(n, _vp) for n in ("mu_w", "rho_w", "mu_b", "rho_b", "prior_mu_w", "prior_sigma_w", "prior_mu_b", "prior_sigma_b", "mu_packed", "sigma_packed")] \
+        + [("prior_kind", C.c_int32), ("reserved", C.c_int32)]
 
 
 class bt_draws(C.Structure):
@@ -48,6 +51,7 @@ _FWD_TAIL = [_vp, C.c_int64, C.POINTER(bt_params), C.POINTER(bt_draws), C.POINTE
 _PROTOS = {
     "bt_version": (C.c_int, []),
     "bt_last_error_string": (C.c_char_p, []),
+    "bt_last_kernel_name": (C.c_char_p, []),
     "bt_reparam_linear_fwd": (C.c_int, [C.c_int32] * 4 + _FWD_TAIL),
     "bt_flipout_linear_fwd": (C.c_int, [C.c_int32] * 4 + _FWD_TAIL),
     "bt_reparam_conv2d_fwd": (C.c_int, [C.POINTER(bt_conv2d_geom), C.c_int32] + _FWD_TAIL),
@@ -106,8 +110,16 @@ def dev_f32(t, what):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def stream_ptr():
-    return torch.cuda.current_stream().cuda_stream
+def stream_ptr(device=None):
+    """The current torch stream OF ``device`` (not of whatever device happens to be current)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def on(device):
+    """Context for a C-ABI launch on tensors of ``device``: the kernels launch on HIP's current device, so make the
+    tensors' device current for the call (a model on cuda:1 while cuda:0 is current would otherwise run on GPU 0
+    against GPU 1's memory, on a stream that orders nothing)."""
+    return torch.cuda.device(device)
 
 
 _ws = {}
@@ -123,9 +135,10 @@ def workspace(key, device):
     return w
 
 
-def kl_normal(segments, layer_ids=None, rho_is_sigma=False, out=None, owner="kl"):
+def kl_normal(segments, layer_ids=None, rho_is_sigma=False, out=None, owner="kl", laplace=False):
     """segments: list of (mu, rho, prior_mu, prior_sigma) device tensors. Returns a 0-dim tensor:
-    sum over layers of (sum over the layer's segments of the element mean)."""
+    sum over layers of (sum over the layer's segments of the element mean).  laplace: kl_div's 'laplace' branch for
+    every segment (the prior tensors are not read, as in the reference)."""
     L = lib()
     dev = segments[0][0].device
     total = None
@@ -147,7 +160,8 @@ def kl_normal(segments, layer_ids=None, rho_is_sigma=False, out=None, owner="kl"
         if layer_ids is not None:
             lay = (C.c_int32 * n)(*layer_ids[c0:c0 + n])
         res = torch.empty((), dtype=torch.float32, device=dev) if (out is None or total is not None) else out
-        check(L.bt_kl_normal(n, arrs[0], arrs[1], arrs[2], arrs[3], numel, lay, KL_RHO_IS_SIGMA if rho_is_sigma else 0,
-                             res.data_ptr(), workspace(owner, dev).data_ptr(), WORKSPACE_BYTES, stream_ptr()))
+        with on(dev):
+            check(L.bt_kl_normal(n, arrs[0], arrs[1], arrs[2], arrs[3], numel, lay, (KL_RHO_IS_SIGMA if rho_is_sigma else 0) | (KL_PRIOR_LAPLACE if laplace else 0),
+                                 res.data_ptr(), workspace(owner, dev).data_ptr(), WORKSPACE_BYTES, stream_ptr(dev)))
         total = res if total is None else total + res
     return total

@@ -122,10 +122,12 @@ class KLNormal(torch.autograd.Function):
     """kl = sum over the given (mu, rho, prior_mu, prior_sigma) groups of mean_i(...), on the HIP KL kernel; grads to mu, rho."""
 
     @staticmethod
-    def forward(ctx, owner, *tensors):
+    def forward(ctx, owner_kind, *tensors):
+        owner, kind = owner_kind
         segs = [tuple(tensors[i:i + 4]) for i in range(0, len(tensors), 4)]
         ctx.save_for_backward(*tensors)
-        return _lib.kl_normal([tuple(t.detach() for t in sg) for sg in segs], layer_ids=[0] * len(segs), owner=owner)
+        ctx.kind = kind
+        return _lib.kl_normal([tuple(t.detach() for t in sg) for sg in segs], layer_ids=[0] * len(segs), owner=owner, laplace=kind == "laplace")
 
     @staticmethod
     def backward(ctx, g):
@@ -135,7 +137,11 @@ class KLNormal(torch.autograd.Function):
             mu, rho, pm, ps = t[i:i + 4]
             n = mu.numel()
             sq = TF.softplus(rho)
-            gmu = (mu - pm) / (ps * ps) * (g / n)
-            grho = (sq / (ps * ps) - 1.0 / sq) * torch.sigmoid(rho) * (g / n)
+            if ctx.kind == "laplace":    # d/dmu E|w| = erf(mu / (sigma sqrt 2)); d/dsigma = sqrt(2/pi) exp(-mu^2 / (2 sigma^2)) - 1/sigma
+                gmu = torch.erf(mu / (sq * 1.4142135623730951)) * (g / n)
+                grho = (0.7978845608028654 * torch.exp(-mu * mu / (2 * sq * sq)) - 1.0 / sq) * torch.sigmoid(rho) * (g / n)
+            else:
+                gmu = (mu - pm) / (ps * ps) * (g / n)
+                grho = (sq / (ps * ps) - 1.0 / sq) * torch.sigmoid(rho) * (g / n)
             grads += [gmu, grho, None, None]
         return tuple(grads)

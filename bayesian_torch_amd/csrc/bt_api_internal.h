@@ -9,6 +9,7 @@
 namespace bt {
 
 int set_error(int code, const char* msg);  // records msg for bt_last_error_string(); returns code
+void note_kernel(const char* name);         // records the kernel instance a fused launch chose (bt_last_kernel_name)
 
 inline int check_launch(const char* who) {
   const hipError_t e = hipGetLastError();

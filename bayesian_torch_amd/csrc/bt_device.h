@@ -116,6 +116,20 @@ __device__ __forceinline__ float kl_term(float mu_q, float sigma_q, float mu_p, 
   return __fsub_rn(__fadd_rn(__fsub_rn(ln_fast(sigma_p), ln_fast(sigma_q)), q), 0.5f);
 }
 
+// One element of kl_div's 'laplace' branch (base_variational_layer.py:74-97): KL(N(mu_q, sigma_q^2) || Laplace(0, 1)) --
+// the reference hard-codes the prior's location 0 and scale 1 there, whatever prior tensors it is handed --
+//   log 2 - 0.5 log(2 pi sigma^2) - 0.5 + E|w|,   E|w| = sigma sqrt(2/pi) exp(-mu^2 / (2 sigma^2)) + mu (1 - 2 Phi(-mu/sigma)),
+// with 1 - 2 Phi(-z) = erf(z / sqrt 2).
+__device__ __forceinline__ float kl_term_laplace(float mu_q, float sigma_q) {
+  const float s2 = __fmul_rn(sigma_q, sigma_q);
+  const float z2 = __fmul_rn(__fmul_rn(mu_q, mu_q), __builtin_amdgcn_rcpf(__fmul_rn(2.0f, s2)));
+  const float g = __builtin_amdgcn_exp2f(__fmul_rn(-1.4426950408889634f, z2));
+  const float z = __fmul_rn(mu_q, __builtin_amdgcn_rcpf(__fmul_rn(sigma_q, 1.4142135623730951f)));
+  const float e_abs = __fadd_rn(__fmul_rn(__fmul_rn(sigma_q, 0.7978845608028654f), g), __fmul_rn(mu_q, erff(z)));
+  const float head = __fsub_rn(__fsub_rn(0.6931471805599453f, __fmul_rn(0.5f, ln_fast(__fmul_rn(6.283185307179586f, s2)))), 0.5f);
+  return __fadd_rn(head, e_abs);
+}
+
 // ---------------------------------------------------------------------------- reductions
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -74,7 +74,12 @@ static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const flo
   a.x_sample_stride = x_sample_stride;
   a.w_vec = linear && ((K & 3) == 0) && al16(p->mu_w) && al16(p->rho_w) && (!d->eps_w || al16(d->eps_w));
   a.x_vec = linear && ((K & 3) == 0) && al16(x) && ((x_sample_stride & 3) == 0) && (!d->sign_in || al16(d->sign_in));
-  a.do_kl = kl_out != nullptr;
+  // The fused KL sweep is the Gaussian closed form. A Laplace-prior layer gets its KL from the standalone kernel, enqueued
+  // right behind the forward on the same stream (same result slot, same workspace).
+  if (p->prior_kind != BT_PRIOR_NORMAL && p->prior_kind != BT_PRIOR_LAPLACE) return bad("unknown prior_kind");
+  const bool kl_after = kl_out && p->prior_kind == BT_PRIOR_LAPLACE;
+  a.do_kl = kl_out != nullptr && !kl_after;
+  if (kl_after) a.kl_out = nullptr;
   a.seed_lo = (uint32_t)d->rng.seed, a.seed_hi = (uint32_t)(d->rng.seed >> 32);
   if (ep) a.ep_scale = ep->scale, a.ep_shift = ep->shift, a.ep_res = ep->residual, a.ep_res_stride = ep->residual_sample_stride, a.ep_relu = ep->relu;
   if (ep && ep->pool != BT_POOL_NONE) {
@@ -94,8 +99,19 @@ static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const flo
   const bool none_inj = !d->eps_w && !d->eps_b && !d->sign_in && !d->sign_out;
   if (!all_inj && !none_inj) return bad("inject all draws of the layer (eps_w, eps_b when biased, both sign tensors for Flipout) or none");
   if (inj && a.ep_pool) return set_error(BT_ERR_UNSUPPORTED, "fused max-pool: not available with injected draws");
-  if (inj) return flip ? launch_flipout_inj(linear, a, (hipStream_t)stream) : launch_reparam_inj(linear, a, (hipStream_t)stream);
-  return flip ? launch_flipout(linear, a, (hipStream_t)stream) : launch_reparam(linear, a, (hipStream_t)stream);
+  int rc;
+  if (inj) rc = flip ? launch_flipout_inj(linear, a, (hipStream_t)stream) : launch_reparam_inj(linear, a, (hipStream_t)stream);
+  else rc = flip ? launch_flipout(linear, a, (hipStream_t)stream) : launch_reparam(linear, a, (hipStream_t)stream);
+  if (rc == BT_OK && kl_after) {
+    const float* mu[2] = {p->mu_w, p->mu_b};
+    const float* rho[2] = {p->rho_w, p->rho_b};
+    const float* pm[2] = {p->prior_mu_w, p->prior_mu_b};
+    const float* ps[2] = {p->prior_sigma_w, p->prior_sigma_b};
+    const int64_t n[2] = {a.w_elems, (int64_t)g.Co};
+    const int32_t lay[2] = {0, 0};
+    rc = bt_kl_normal(p->mu_b ? 2 : 1, mu, rho, pm, ps, n, lay, BT_KL_PRIOR_LAPLACE, kl_out, ws, ws_bytes, stream);
+  }
+  return rc;
 }
 
 static bt_conv2d_geom linear_geom(int B, int In, int Out) {

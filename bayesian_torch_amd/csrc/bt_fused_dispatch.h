@@ -85,6 +85,12 @@ static int launch_fast(const FwdArgs& a, hipStream_t stream) {
   auto fk = fused_fast_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, false, XMODE, NPW, POOL>;
   static bool fflags[64] = {};
   if (int rc = ensure_lds(fk, lds, fflags)) return rc;
+  {
+    char nm[160];
+    snprintf(nm, sizeof(nm), "fused_fast_kernel<%d,%d,%d,%s,%s,%s,inj=0,xmode=%d,npw=%d,pool=%d>", BN, BM, CWN, FLIP ? "flip" : "reparam",
+             LINEAR ? "linear" : "conv", TRANS ? "trans" : "notrans", XMODE, NPW, POOL ? 1 : 0);
+    note_kernel(nm);
+  }
   hipLaunchKernelGGL(fk, dim3((unsigned)a.total_blocks), dim3(256 + 64 * NPW), lds, stream, a);
   return check_launch("fused forward (fast)");
 }
@@ -134,6 +140,12 @@ static int launch_cfg(FwdArgs& a, hipStream_t stream) {
     auto kern = fused_fwd_kernel<BN, BM, CWN, FLIP, LINEAR, TRANS, INJ>;
     static bool gflags[64] = {};
     if (int rc = ensure_lds(kern, lds, gflags)) return rc;
+    {
+      char nm[160];
+      snprintf(nm, sizeof(nm), "fused_fwd_kernel<%d,%d,%d,%s,%s,%s,inj=%d>", BN, BM, CWN, FLIP ? "flip" : "reparam", LINEAR ? "linear" : "conv",
+               TRANS ? "trans" : "notrans", INJ ? 1 : 0);
+      note_kernel(nm);
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(kThreads), lds, stream, a);
     return check_launch("fused forward");
   } else {

@@ -17,6 +17,7 @@ struct KlSegs {
   unsigned long long new_layer;             // bit i: segment i starts a new layer (fp32 summation grouping)
   int nseg;
   int rho_is_sigma;
+  int laplace;  // 'laplace' branch of kl_div (prior tensors are ignored, as in the reference) instead of the Gaussian closed form
 };
 
 constexpr int kKlThreads = 256;
@@ -42,6 +43,8 @@ __global__ __launch_bounds__(kKlThreads) void kl_normal_kernel(KlSegs sg, float*
 
   const bool is_sigma = sg.rho_is_sigma != 0;
   auto sig = [&](float v) { return is_sigma ? v : softplus(v); };
+  const bool lap = sg.laplace != 0;
+  auto kl_term = [&](float mq, float sq, float mp, float sp) { return lap ? kl_term_laplace(mq, sq) : bt::kl_term(mq, sq, mp, sp); };
   double acc = 0.0;
   const long long n4 = vec_ok ? (n >> 2) : 0;  // float4 groups
   for (long long base = (long long)lb * (kKlThreads * kKlVecPerThread); base < n4; base += (long long)nb * (kKlThreads * kKlVecPerThread)) {
@@ -122,6 +125,7 @@ extern "C" int bt_kl_normal(int32_t n_segments, const float* const* mu, const fl
   sg.first_block[n_segments] = blocks;
   sg.nseg = n_segments;
   sg.rho_is_sigma = (flags & BT_KL_RHO_IS_SIGMA) ? 1 : 0;
+  sg.laplace = (flags & BT_KL_PRIOR_LAPLACE) ? 1 : 0;
   sg.new_layer = 0;
   for (int i = 0; i < n_segments; ++i) {
     if (layer_of_segment && i && layer_of_segment[i] < layer_of_segment[i - 1]) return set_error(BT_ERR_BAD_ARG, "bt_kl_normal: layer_of_segment must be non-decreasing");

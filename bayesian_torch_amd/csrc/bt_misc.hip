@@ -7,6 +7,12 @@ namespace bt {
 
 static thread_local char g_err[512] = "";
 
+static thread_local char g_kname[160] = "";
+void note_kernel(const char* name) {
+  strncpy(g_kname, name, sizeof(g_kname) - 1);
+  g_kname[sizeof(g_kname) - 1] = 0;
+}
+
 int set_error(int code, const char* msg) {
   strncpy(g_err, msg, sizeof(g_err) - 1);
   g_err[sizeof(g_err) - 1] = 0;
@@ -113,6 +119,7 @@ __global__ __launch_bounds__(256) void mc_epilogue_kernel(int S, int B, int C, c
 }  // namespace bt
 
 extern "C" int bt_version(void) { return BT_VERSION; }
+extern "C" const char* bt_last_kernel_name(void) { return bt::g_kname; }
 extern "C" const char* bt_last_error_string(void) { return bt::g_err; }
 
 extern "C" int bt_rng_normal_fill(const bt_rng* rng, uint32_t tensor_id, int32_t S, int64_t rows, int64_t inner, int64_t taps, float* out,

@@ -26,13 +26,14 @@ def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, pool=False, **kw):
 def _fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=None, S=1, shared_x=True,
                    priors=None, eps_w=None, eps_b=None, sign_in=None, sign_out=None,
                    seed=0, call=0, layer_id=0, sample0=0, call_base=None, want_kl=False, workspace_owner="functional",
-                   post_scale=None, post_shift=None, residual=None, relu=False, packed=None, pool=False):
+                   post_scale=None, post_shift=None, residual=None, relu=False, packed=None, pool=False, prior_type="normal"):
     """x: [B, In] (conv=None) or [B, Ci, H, W]; when ``shared_x`` is False x holds S stacked batches
     ([S*B, ...]).  conv: dict(stride=(sh,sw), padding=(ph,pw), dilation=(dh,dw), groups=g) for Conv2d.
     priors: (prior_mu_w, prior_sigma_w, prior_mu_b, prior_sigma_b) -- required when want_kl.
     eps_*/sign_*: injected draws with a leading S axis, or None for the on-chip generators.
     post_scale/post_shift [Co], residual ([S*B, ...] like out, or [B, ...] shared), relu: fused output stage
     (v*scale+shift, +residual, max(.,0)).  packed: (mu_packed, sigma_packed) from pack_params() -- selects the fast kernel.
+    prior_type: "normal" | "laplace" (kl_div's branch; only matters when want_kl).
     Returns (out [S*B, ...], kl or None)."""
     x = _lib.dev_f32(x, "input")
     dev = x.device
@@ -79,7 +80,8 @@ def _fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=No
         kl = torch.empty((), dtype=torch.float32, device=dev)
         ws = _lib.workspace(workspace_owner, dev)
     P = _lib.bt_params(tens["mu_w"].data_ptr(), tens["rho_w"].data_ptr(), _lib.ptr(tens["mu_b"]), _lib.ptr(tens["rho_b"]),
-                       _lib.ptr(pr[0]), _lib.ptr(pr[1]), _lib.ptr(pr[2]), _lib.ptr(pr[3]), _lib.ptr(tens["mu_packed"]), _lib.ptr(tens["sigma_packed"]))
+                       _lib.ptr(pr[0]), _lib.ptr(pr[1]), _lib.ptr(pr[2]), _lib.ptr(pr[3]), _lib.ptr(tens["mu_packed"]), _lib.ptr(tens["sigma_packed"]),
+                       _lib.PRIOR_LAPLACE if prior_type == "laplace" else _lib.PRIOR_NORMAL, 0)
     R = _lib.bt_rng(int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(call_base), int(call) & 0xFFFFFFFF, int(layer_id), int(sample0), 0)
     D = _lib.bt_draws(_lib.ptr(tens["eps_w"]), _lib.ptr(tens["eps_b"]), _lib.ptr(tens["sign_in"]), _lib.ptr(tens["sign_out"]), R)
     E = None
@@ -94,17 +96,18 @@ def _fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=No
             raise RuntimeError("post_scale / post_shift must both have Co elements")
         E = C.byref(_lib.bt_epilogue(_lib.ptr(tens["post_scale"]), _lib.ptr(tens["post_shift"]), _lib.ptr(res), rstride, 1 if relu else 0, 1 if pool else 0))
     tail_args = (x.data_ptr(), 0 if shared_x else x_elems, C.byref(P), C.byref(D), E, out.data_ptr(), _lib.ptr(kl), _lib.ptr(ws),
-                 _lib.WORKSPACE_BYTES if want_kl else 0, _lib.stream_ptr())
+                 _lib.WORKSPACE_BYTES if want_kl else 0, _lib.stream_ptr(dev))
     L = _lib.lib()
-    if conv is None:
-        fn = L.bt_flipout_linear_fwd if flip else L.bt_reparam_linear_fwd
-        _lib.check(fn(B, In, Co, S, *tail_args))
-    else:
-        fn = L.bt_flipout_conv2d_fwd if flip else L.bt_reparam_conv2d_fwd
-        rc = fn(C.byref(geom), S, *tail_args)
-        if pool and rc == _lib.ERR_UNSUPPORTED:
-            return None
-        _lib.check(rc)
+    with _lib.on(dev):
+        if conv is None:
+            fn = L.bt_flipout_linear_fwd if flip else L.bt_reparam_linear_fwd
+            _lib.check(fn(B, In, Co, S, *tail_args))
+        else:
+            fn = L.bt_flipout_conv2d_fwd if flip else L.bt_reparam_conv2d_fwd
+            rc = fn(C.byref(geom), S, *tail_args)
+            if pool and rc == _lib.ERR_UNSUPPORTED:
+                return None
+            _lib.check(rc)
     return out, kl
 
 
@@ -122,7 +125,8 @@ def rng_fill_normal(seed, call, layer_id, sample0, tensor_id, S, shape, device, 
         taps *= d
     out = torch.empty((S,) + shape, dtype=torch.float32, device=device)
     R = _rng(seed, call, layer_id, sample0, call_base)
-    _lib.check(_lib.lib().bt_rng_normal_fill(C.byref(R), tensor_id, S, rows, inner, taps, out.data_ptr(), _lib.stream_ptr()))
+    with _lib.on(out.device):
+        _lib.check(_lib.lib().bt_rng_normal_fill(C.byref(R), tensor_id, S, rows, inner, taps, out.data_ptr(), _lib.stream_ptr(out.device)))
     return out
 
 
@@ -134,7 +138,8 @@ def rng_fill_sign(seed, call, layer_id, sample0, tensor_id, S, shape, device, ca
         n *= d
     out = torch.empty((S,) + shape, dtype=torch.float32, device=device)
     R = _rng(seed, call, layer_id, sample0, call_base)
-    _lib.check(_lib.lib().bt_rng_sign_fill(C.byref(R), tensor_id, S, n, out.data_ptr(), _lib.stream_ptr()))
+    with _lib.on(out.device):
+        _lib.check(_lib.lib().bt_rng_sign_fill(C.byref(R), tensor_id, S, n, out.data_ptr(), _lib.stream_ptr(out.device)))
     return out
 
 
@@ -149,7 +154,8 @@ def pack_params(mu_w, rho_w):
     C4 = (Ci + 3) // 4 * 4
     mp = torch.empty((Co, taps, C4), dtype=torch.float32, device=mu_w.device)
     sp = torch.empty_like(mp)
-    _lib.check(_lib.lib().bt_pack_params(mu_w.data_ptr(), rho_w.data_ptr(), Co, Ci, taps, mp.data_ptr(), sp.data_ptr(), _lib.stream_ptr()))
+    with _lib.on(mu_w.device):
+        _lib.check(_lib.lib().bt_pack_params(mu_w.data_ptr(), rho_w.data_ptr(), Co, Ci, taps, mp.data_ptr(), sp.data_ptr(), _lib.stream_ptr(mu_w.device)))
     return mp, sp
 
 
@@ -158,5 +164,6 @@ def mc_epilogue(logits):
     logits = _lib.dev_f32(logits, "logits")
     S, B, Cc = logits.shape
     packed = torch.empty(B * Cc + B + B * Cc, dtype=torch.float32, device=logits.device)
-    _lib.check(_lib.lib().bt_mc_epilogue(S, B, Cc, logits.data_ptr(), packed.data_ptr(), _lib.stream_ptr()))
+    with _lib.on(logits.device):
+        _lib.check(_lib.lib().bt_mc_epilogue(S, B, Cc, logits.data_ptr(), packed.data_ptr(), _lib.stream_ptr(logits.device)))
     return packed

@@ -50,13 +50,13 @@ class FusedBayesLayer(BaseVariationalLayer_):
             self.register_parameter("rho_bias", None)
             for b in ("eps_bias", "prior_bias_mu", "prior_bias_sigma"):
                 self.register_buffer(b, None, persistent=False)
-        self._layer_id = rng.new_layer_id()
+        self._layer_id = rng.new_layer_id()   # unique per constructed layer; dnn_to_bnn / rng.assign_layer_ids renumber by position
+        self._sigma_cache = None   # ((versions, pointers), (mu_packed, sigma_packed)): a pure function of (mu, rho)
         self._last = None
         self.post_relu = False    # fused output stage, set by bayesian_torch_amd.fuse (inference-time folding)
         self.post_pool = False    # ... followed by MaxPool2d(3, 2, 1) (fuse.fold_maxpool: the ResNet stem)
         self.register_buffer("post_scale", None, persistent=False)
         self.register_buffer("post_shift", None, persistent=False)
-        self._sigma_cache = None   # ((versions, pointers), (mu_packed, sigma_packed)): a pure function of (mu, rho)
         self.inject_draw = None   # test hook: dict(eps_w [S,*w], eps_b, sign_in, sign_out) consumed instead of a fresh draw (or a list of them)
         self.init_parameters()
         self.quant_prepare = False
@@ -67,7 +67,19 @@ class FusedBayesLayer(BaseVariationalLayer_):
             mu0, rho0 = mu0[0], rho0[0]
         return mu0, rho0
 
+    def invalidate_pack(self):
+        """Drop the packed (mu, sigma) copy the fast kernel reads. Needed after writing a parameter through ``.data``
+        (``p.data.copy_()`` / ``.normal_()`` do not bump ``p._version``, which is what the cache is keyed on);
+        init_parameters, MOPED initialisation and load_state_dict call it themselves. A captured ``McGraph`` bakes the
+        pack's address in: re-capture after a parameter update."""
+        self._sigma_cache = None
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._sigma_cache = None
+
     def init_parameters(self):
+        self._sigma_cache = None
         mu0, rho0 = self._init_scalars()
         self.prior_weight_mu.fill_(self.prior_mean)
         self.prior_weight_sigma.fill_(self.prior_variance)      # "variance" is used as sigma_p, as in the reference
@@ -92,19 +104,28 @@ class FusedBayesLayer(BaseVariationalLayer_):
             segs.append((self.mu_bias, self.rho_bias, self.prior_bias_mu, self.prior_bias_sigma))
         return segs
 
+    def _prior_kind(self):
+        return check_prior_type(getattr(self, "prior_type", "normal"))
+
     def kl_loss(self):
-        check_prior_type(getattr(self, "prior_type", "normal"))
+        kind = self._prior_kind()
         segs = self._kl_segments()
         if torch.is_grad_enabled() and any(t.requires_grad for sg in segs for t in sg):
             from ..autograd import KLNormal
-            return KLNormal.apply(("layer", self._layer_id), *[t for sg in segs for t in sg])
-        return _lib.kl_normal(segs, layer_ids=[0] * len(segs), owner=("layer", self._layer_id))
+            return KLNormal.apply((("layer", self._layer_id), kind), *[t for sg in segs for t in sg])
+        return _lib.kl_normal(segs, layer_ids=[0] * len(segs), owner=("layer", self._layer_id), laplace=kind == "laplace")
 
     # ------------------------------------------------------------------ forward
     def _packed(self):
-        """(mu_packed, sigma_packed): tap-major copies of (mu, softplus(rho)) for the fast kernel, rebuilt when a
-        parameter changes (in-place updates bump ._version; a new tensor changes data_ptr)."""
+        """(mu_packed, sigma_packed): tap-major copies of (mu, softplus(rho)) for the fast kernel. Cached only for
+        inference (module in eval mode or grad disabled), keyed on the parameters' versions and addresses (in-place
+        autograd-visible updates bump ._version; a new tensor changes data_ptr); writes through ``.data`` bypass the
+        version counter -- see invalidate_pack(). While training with grad enabled the pack is rebuilt on every call
+        (one cheap kernel), so an optimizer step or a ``.data`` update can never leave the forward on stale weights."""
         mu, rho = self._w("mu"), self._w("rho")
+        if self.training and torch.is_grad_enabled():
+            self._sigma_cache = None
+            return F.pack_params(mu.detach(), rho.detach())
         key = (mu._version, mu.data_ptr(), rho._version, rho.data_ptr())
         c = self._sigma_cache
         if c is None or c[0] != key:
@@ -130,8 +151,7 @@ class FusedBayesLayer(BaseVariationalLayer_):
         ctx = mc.current()
         collect = ctx is not None and ctx.collect_kl
         want_kl = return_kl or collect
-        if want_kl:
-            check_prior_type(getattr(self, "prior_type", "normal"))
+        kind = self._prior_kind() if want_kl else "normal"
         x = _lib.dev_f32(x, "input")
         lead = None
         if self._kind == "linear":
@@ -196,7 +216,7 @@ class FusedBayesLayer(BaseVariationalLayer_):
             kl = None
             if want_kl:
                 flat = [t for sg in self._kl_segments() for t in sg]
-                kl = KLNormal.apply(("layer", self._layer_id), *flat)
+                kl = KLNormal.apply((("layer", self._layer_id), kind), *flat)
         else:
             priors = (self.prior_weight_mu, self.prior_weight_sigma, self.prior_bias_mu, self.prior_bias_sigma) if want_kl else None
             out, kl = F.fused_forward(x, mu_t, rho_t, self.mu_bias, self.rho_bias, flip=self._flip, conv=conv,
@@ -204,12 +224,13 @@ class FusedBayesLayer(BaseVariationalLayer_):
                                       sign_in=draw.get("sign_in"), sign_out=draw.get("sign_out"), seed=seed, call=call,
                                       layer_id=self._layer_id, sample0=sample0, call_base=call_base, want_kl=want_kl,
                                       workspace_owner=("layer", self._layer_id), post_scale=self.post_scale, post_shift=self.post_shift,
-                                      residual=residual, relu=self.post_relu, pool=self.post_pool, packed=self._packed())
+                                      residual=residual, relu=self.post_relu, pool=self.post_pool, packed=self._packed(), prior_type=kind)
         conv_shape = tuple(out.shape[1:])     # shape of one sample's contraction output (sign_out's shape): before any fused pooling
         if self.post_pool and conv is not None:
             conv_shape = (out.shape[1],) + F.conv_out_hw(x.shape[2], x.shape[3], mu_t.shape[2], mu_t.shape[3], *conv["stride"],
                                                          *conv["padding"], *conv["dilation"])
         self._last = dict(draw=draw or None, rng=(seed, call_base, call, self._layer_id, sample0), S=S,
+                          kernel=_lib.lib().bt_last_kernel_name().decode(),
                           x_shape=(B,) + tuple(x.shape[1:]), out_shape=(B,) + conv_shape)
         if lead is not None:
             out = out.reshape(lead + (self.out_features,))

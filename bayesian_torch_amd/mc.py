@@ -60,9 +60,12 @@ def mc_forward(model, x, S, sample0=0, with_kl=True):
 
 class McGraph:
     """``mc_forward`` (+ the MC epilogue) captured once in a HIP graph and replayed per batch: the ~25 kernel launches of a
-    model become one graph launch.  The draws stay fresh: every fused kernel adds a device-side counter (``call_base``,
-    bt_rng.call_base_dev) to its baked-in ``call`` coordinate and the graph itself advances that counter by the number of
-    layer calls at its end -- replay r uses exactly the coordinates eager call r would have used.
+    model become one graph launch.  The draws stay fresh: every fused kernel adds a device-side word (``call_base``,
+    bt_rng.call_base_dev) to its baked-in ``call`` coordinate, and ``replay()`` sets that word so that the replay draws at the
+    host counter's current position and then advances the host counter by the number of layer calls -- a replay consumes
+    exactly the coordinates an eager ``mc_forward`` at that moment would have, so eager calls, replays and several graphs
+    can interleave without ever reusing a draw.  Parameters are baked in by address (including the layers' packed copies):
+    re-capture after a parameter update.
     ("capturing the whole model per sample in a HIP graph".)"""
 
     def __init__(self, model, x, S, sample0=0, with_kl=True, epilogue=True):
@@ -89,14 +92,20 @@ class McGraph:
             run()
             self.calls_per_run = rng.peek_call() - c0
         torch.cuda.current_stream().wait_stream(side)
+        self.call0 = rng.peek_call()           # the call coordinate baked into the first captured layer
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.logits, self.kl, self.packed = run()
-            self.call_base.add_(self.calls_per_run)
+        rng.set_call(self.call0)               # capture executes nothing: its coordinates are still unused
 
     def replay(self, x=None):
         """-> (logits [S, B, ...], kl, packed epilogue sums) -- tensors owned by the graph, overwritten by the next replay."""
+        from . import rng
         if x is not None:
             self.x.copy_(x)
+        c = rng.peek_call()
+        d = (c - self.call0) & 0xFFFFFFFF          # the device adds the word mod 2^32; the tensor holds it as int32
+        self.call_base.fill_(d - (1 << 32) if d >= (1 << 31) else d)
         self.graph.replay()
+        rng.set_call(c + self.calls_per_run)
         return self.logits, self.kl, self.packed

@@ -53,10 +53,10 @@ def mc_predict(model, x, S_total, sample0=0, group=None, with_kl=True):
     from .mc import mc_forward
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if S_total < world:      # checked identically on every rank BEFORE any work: all ranks raise together, none enters the collective
+        raise RuntimeError(f"S_total={S_total} is smaller than the world size {world}: every rank needs at least one sample")
     first, count = shard(S_total, rank, world)
     B = x.shape[0]
-    if count <= 0:
-        raise RuntimeError(f"S_total={S_total} is smaller than the world size {world}")
     logits, kl = mc_forward(model, x, count, sample0=sample0 + first, with_kl=with_kl)
     logits = logits.reshape(count, B, -1)
     packed = F.mc_epilogue(logits)

@@ -7,13 +7,14 @@ Same contract: in-place recursive swap of leaf modules whose class name contains
 (mu, rho, prior) tensors into ONE bt_kl_normal launch instead of ~12 ATen passes per layer.
 """
 import bayesian_torch_amd.layers as bayesian_layers
-from bayesian_torch_amd import _lib
+from bayesian_torch_amd import _lib, rng
 from bayesian_torch_amd.layers._fused import FusedBayesLayer
 from bayesian_torch_amd.layers.base_variational_layer import check_prior_type
 from bayesian_torch_amd.utils.util import get_rho
 
 
 def _moped(layer, d, delta):
+    layer.invalidate_pack()
     w = layer._w("mu")
     w.data.copy_(d.weight.data)
     layer._w("rho").data.copy_(get_rho(d.weight.data, delta))
@@ -70,22 +71,28 @@ def dnn_to_bnn(m, bnn_prior_parameters):
             setattr(m, name, bnn_linear_layer(bnn_prior_parameters, child))
         elif "LSTM" in cname:
             setattr(m, name, bnn_lstm_layer(bnn_prior_parameters, child))
+    # RNG coordinate of every Bayesian layer = its position in the model (the outermost call of the recursion has the last
+    # word): draws then depend on (seed, call, position, sample), not on how many layers the process built before.
+    rng.assign_layer_ids(m)
     return
 
 
 def get_kl_loss(m):
     """Sum of ``layer.kl_loss()`` over every module that has one; None without Bayesian layers."""
-    segs, lids, others = [], [], []
+    segs, lids, others, lap = [], [], [], []
     n = 0
     for layer in m.modules():
         if isinstance(layer, FusedBayesLayer):
-            check_prior_type(getattr(layer, "prior_type", "normal"))
+            if check_prior_type(getattr(layer, "prior_type", "normal")) == "laplace":
+                lap.append(layer)          # (rare) its own launch: one bt_kl_normal call takes one prior kind
+                continue
             s = layer._kl_segments()
             segs += s
             lids += [n] * len(s)
             n += 1
         elif hasattr(layer, "kl_loss"):
             others.append(layer)
+    others = lap + others
     kl = None
     if segs:
         import torch

@@ -41,6 +41,19 @@ def new_layer_id():
     return _layer_counter[0]
 
 
+def assign_layer_ids(model, first=1):
+    """Number the Bayesian layers of ``model`` by position (``model.modules()`` order): layer_id is the RNG coordinate
+    that separates the layers' draw streams, so two copies of a model (``copy.deepcopy``, or the same architecture built
+    twice in any order) draw identically for the same (seed, call).  ``dnn_to_bnn`` calls this; call it yourself for a
+    hand-assembled model of ``bayesian_torch_amd.layers`` modules if construction-order independence matters."""
+    n = first
+    for m in model.modules():
+        if hasattr(m, "_layer_id") and hasattr(m, "_kl_segments"):
+            m._layer_id = n
+            n += 1
+    return n - first
+
+
 def manual_seed(seed):
     """Pin the Philox seed explicitly (otherwise torch.initial_seed() is followed)."""
     _state.seed = int(seed) & 0xFFFFFFFFFFFFFFFF

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BT_VERSION 100
+#define BT_VERSION 200
 #define BT_WORKSPACE_BYTES 65536
 
 #define BT_OK 0
@@ -76,7 +76,11 @@ typedef struct bt_params {
    * 16-byte load at the byte offset of its draw index, pruned taps are never touched in memory, and the kernel does no
    * softplus. Both NULL: the general kernel reads the natural layout. */
   const float *mu_packed, *sigma_packed;
+  int32_t prior_kind; /* BT_PRIOR_NORMAL (kl_div 'normal'), BT_PRIOR_LAPLACE (kl_div 'laplace': base_variational_layer.py:74-97) */
+  int32_t reserved;
 } bt_params;
+#define BT_PRIOR_NORMAL 0
+#define BT_PRIOR_LAPLACE 1
 
 /* Injected draws (NULL => generate on chip). Layouts: eps_w [S][Co*K],
  * eps_b [S][Co], sign_in [S][elements of one sample's x], sign_out
@@ -118,6 +122,9 @@ typedef struct bt_epilogue {
 
 int bt_version(void);
 const char *bt_last_error_string(void);
+/* Diagnostic: the kernel instance (template name and tile) the calling thread's last fused-forward launch selected --
+ * lets a benchmark attribute per-launch times to kernel instances the way rocprofv3's kernel trace does. */
+const char *bt_last_kernel_name(void);
 
 /* a5: LinearReparameterization.forward  (layers/variational_layers/linear_variational.py:160-181)
  *   out[s][b][o] = sum_k x_s[b][k] * (mu_w + log1p(exp(rho_w)) * eps_w[s])[o][k] + (mu_b + log1p(exp(rho_b)) * eps_b[s])[o]
@@ -158,6 +165,9 @@ int bt_flipout_conv2d_fwd(const bt_conv2d_geom *g, int32_t S,
  * a whole model's layers can go in one call). Segment arrays are HOST arrays. */
 #define BT_KL_MAX_SEGMENTS 64
 #define BT_KL_RHO_IS_SIGMA 1u /* flags: the `rho` arrays already hold sigma (kl_div() called directly) */
+#define BT_KL_PRIOR_LAPLACE 2u /* flags: kl_div's 'laplace' branch (base_variational_layer.py:74-97) for every segment:
+                                  mean_i( log 2 - 0.5 log(2 pi sq^2) - 0.5 + E|w_i| ) against Laplace(0, 1) -- the reference
+                                  hard-codes that prior and ignores the prior tensors; so does this flag (pass any valid tensors) */
 int bt_kl_normal(int32_t n_segments, const float *const *mu, const float *const *rho,
                  const float *const *prior_mu, const float *const *prior_sigma, const int64_t *numel,
                  const int32_t *layer_of_segment /* host, non-decreasing, or NULL: the fp32 sum is formed as

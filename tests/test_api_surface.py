@@ -154,7 +154,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), name
     L = _lib.lib()
-    assert L.bt_version() == 100
+    assert L.bt_version() == 200
     # host-only entry: Philox4x32-10 known answers (Random123 kat_vectors)
     def philox(ctr, key):
         c = (ctypes.c_uint32 * 4)(*ctr)
@@ -170,7 +170,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from bayesian_torch_amd import _lib
-    assert ctypes.sizeof(_lib.bt_rng) == 32 and ctypes.sizeof(_lib.bt_params) == 80
+    assert ctypes.sizeof(_lib.bt_rng) == 32 and ctypes.sizeof(_lib.bt_params) == 88
     assert ctypes.sizeof(_lib.bt_draws) == 64 and ctypes.sizeof(_lib.bt_conv2d_geom) == 56 and ctypes.sizeof(_lib.bt_epilogue) == 40
 
 

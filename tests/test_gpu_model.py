@@ -194,8 +194,9 @@ def test_fused_output_stage_equals_unfused_model(btype):
 
 
 def test_mc_graph_replay_matches_eager_and_draws_fresh_samples():
-    """HIP-graph runner: replay r reproduces what eager call r computes (same RNG coordinates through the device-side
-    call counter), and consecutive replays differ."""
+    """HIP-graph runner: a replay computes what an eager mc_forward at the same position of the call counter computes
+    (device-side call word), consecutive replays differ, and replays / eager calls / a second graph interleave without
+    ever reusing a draw coordinate (the host counter advances with every replay)."""
     from bayesian_torch_amd import rng
     from bayesian_torch_amd.mc import McGraph, mc_forward
     meta = dict(x_shape=[6, 3, 32, 32], seed=13, btype="Reparameterization", S=3)
@@ -204,23 +205,26 @@ def test_mc_graph_replay_matches_eager_and_draws_fresh_samples():
     rng.set_mode("philox")
     rng.manual_seed(21)
     g = McGraph(net, x, 3, sample0=4)
-    base = rng.peek_call() - g.calls_per_run          # call coordinate the captured kernels carry
-    l1, kl1, _ = g.replay()
-    l1, kl1 = l1.clone(), kl1.clone()
-    l2, _, _ = g.replay()
-    l2 = l2.clone()
-    assert not torch.equal(l1, l2)
-    for r, want in ((1, l1), (2, l2)):                # call_base starts at 0 and is advanced by the capture run's own add_? no:
-        rng.set_call(base + r * g.calls_per_run)      # the capture pass does not execute kernels, so replay #1 sees call_base = 0
-        e, ekl = mc_forward(net, x, 3, sample0=4)
-        if r == 1:
-            rng.set_call(base)
-            e0, _ = mc_forward(net, x, 3, sample0=4)
-            assert torch.equal(e0, l1)
-            assert_close(ekl.cpu(), kl1.cpu(), 1e-6, 0, "kl")
-    rng.set_call(base + g.calls_per_run)
-    e1, _ = mc_forward(net, x, 3, sample0=4)
-    assert torch.equal(e1, l2)
+    seen = []
+    for r in range(3):
+        c = rng.peek_call()
+        l, kl, _ = g.replay()
+        l, kl = l.clone(), kl.clone()
+        assert rng.peek_call() == c + g.calls_per_run
+        rng.set_call(c)
+        e, ekl = mc_forward(net, x, 3, sample0=4)          # eager at the same coordinates
+        assert torch.equal(e, l)
+        assert_close(ekl.cpu(), kl.cpu(), 1e-6, 0, "kl")
+        assert all(not torch.equal(l, p) for p in seen)
+        seen.append(l)
+    e, _ = mc_forward(net, x, 3, sample0=4)                # eager after the replays: fresh coordinates
+    assert all(not torch.equal(e, p) for p in seen)
+    seen.append(e.clone())
+    g2 = McGraph(net, x, 3, sample0=4)                     # a second graph of the same model, interleaved with the first
+    for gr in (g2, g, g2, g):
+        l = gr.replay()[0].clone()
+        assert all(not torch.equal(l, p) for p in seen)
+        seen.append(l)
 
 
 @pytest.mark.parametrize("btype", ["Reparameterization", "Flipout"])

@@ -65,3 +65,34 @@ def test_two_rank_packed_allreduce():
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(2))
     assert got == [(0, True), (1, True)]
+
+
+def _worker_small(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        try:
+            mc_dist.mc_predict(None, torch.zeros(2, 3), 1)      # S_total = 1 < world = 2: refused before any work, on EVERY rank
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, "raised" if "smaller than the world size" in str(e) else repr(e)))
+        dist.barrier()                                          # nobody is stuck in a collective
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_fewer_samples_than_ranks_raises_on_every_rank():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_small, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=90) for _ in range(2))
+    for p in procs:
+        p.join(30)
+    assert got == {0: "raised", 1: "raised"}, got
