@@ -10,7 +10,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbtorch_hip.so")
+LIB_PATH = os.environ.get("BT_LIB_PATH") or os.path.join(_HERE, "libbtorch_hip.so")   # BT_LIB_PATH: a diagnostic build (tools/stamps.py)
 WORKSPACE_BYTES = 65536
 KL_MAX_SEGMENTS = 64
 KL_RHO_IS_SIGMA = 1
@@ -52,6 +52,7 @@ _PROTOS = {
     "bt_version": (C.c_int, []),
     "bt_last_error_string": (C.c_char_p, []),
     "bt_last_kernel_name": (C.c_char_p, []),
+    "bt_set_contraction": (C.c_int, [C.c_int]),
     "bt_reparam_linear_fwd": (C.c_int, [C.c_int32] * 4 + _FWD_TAIL),
     "bt_flipout_linear_fwd": (C.c_int, [C.c_int32] * 4 + _FWD_TAIL),
     "bt_reparam_conv2d_fwd": (C.c_int, [C.POINTER(bt_conv2d_geom), C.c_int32] + _FWD_TAIL),

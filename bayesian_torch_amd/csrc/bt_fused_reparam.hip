@@ -1,4 +1,12 @@
 #include "bt_fused_dispatch.h"
 namespace bt {
-int launch_reparam(bool linear, FwdArgs& a, hipStream_t stream) { return launch_flavour<false, false>(linear, a, stream); }
+int launch_split(FwdArgs& a, hipStream_t stream);  // bt_fused_split.hip: 0 taken, 1 not applicable, < 0 error
+int launch_reparam(bool linear, FwdArgs& a, hipStream_t stream) {
+  if (!linear) {
+    FwdArgs b = a;
+    const int rc = launch_split(b, stream);
+    if (rc <= 0) return rc;
+  }
+  return launch_flavour<false, false>(linear, a, stream);
+}
 }  // namespace bt

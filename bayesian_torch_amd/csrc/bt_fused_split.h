@@ -1,0 +1,571 @@
+// Split-precision flavour of the fused forward: the fp32 contraction as exact bf16 pieces on the bf16 matrix pipe.
+//
+// gfx950 runs fp32-input MFMA at the VECTOR rate (64 FLOP/clk/SIMD) and an fp32 MFMA blocks the SIMD's VALU issue, so
+// the fp32 kernels (bt_fused_fast.h) are bound by t_MFMA + t_VALU. v_mfma_f32_32x32x16_bf16 has 16x the rate and holds
+// the VALU issue for only 8 of its 32 cycles. Here every fp32 operand value v is cut into NP bf16 pieces,
+//     v = h + m (+ l),   h = top 16 bits of v,   m = top 16 bits of (v - h),   l = v - h - m
+// (each difference is exact in fp32, and with NP = 3 the three pieces hold all 24 significant bits: the split is
+// EXACT), and a product x*w becomes the sum of the piece products of weight >= 2^-16:
+//     NP = 3, 6 terms:  xh*wh + xh*wm + xm*wh + xh*wl + xm*wm + xl*wh        (dropped terms <= 2^-24 |x*w|: fp32 level)
+//     NP = 2, 3 terms:  xh*wh + xh*wm + xm*wh                                   (dropped terms <= 2^-15 |x*w|: opt-in)
+// Each piece product is exact in fp32 (8 x 8 significant bits) and the MFMA accumulates in fp32, so the 6-term form
+// has the accuracy of the fp32 FMA chain at 6/16 of its matrix-pipe time, with the weight synthesis co-issuing.
+//
+// Same algorithm, same draw stream (tap-major Philox blocks, one block = 4 channels of one tap), same KL sweep and
+// output stage as bt_fused_fast.h; what changes is the K order and the LDS images.
+//   * K order (canonical, independent of the tile): channels in OCTETS of 8; an MFMA step covers two (octet, active tap)
+//     entries -- lanes 0-31 hold the 8 channels of the first, lanes 32-63 of the second. nA > 1: the octet's taps in
+//     pairs (a0,a1), (a2,a3) ...; an odd last tap runs with an empty second half. nA == 1: consecutive octets in pairs.
+//   * x tile: the LDS patch of the fast kernel, but channel-last -- X[octet][patch pixel][piece][8 channels] bf16, 16*NP
+//     bytes per pixel, so an operand fragment (8 channels of one pixel, one piece) is ONE ds_read_b128 at
+//     pixel(lane) + tap offset(step, lane half), and the three pieces are immediates apart.
+//   * w tile: W[step][lane half][piece][row][8 channels] bf16 -- 16 consecutive rows cover all 64 banks.
+// Producers split every sampled weight and every staged activation once; consumers only read LDS and issue MFMAs.
+#pragma once
+#include "bt_fused_fwd.h"
+
+namespace bt {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kSplitSteps = 5;  // MFMA K16-steps per barrier stage (9 taps of one octet = 5 steps)
+
+template <int BM>
+constexpr int split_xpo() {  // pixel-octets one x buffer holds (8 images of a 10x10 patch = 800; 16 of a 6x6 = 576)
+  return BM >= 512 ? 832 : 640;
+}
+template <int BN, int NP>
+constexpr int split_w_bytes() { return kSplitSteps * 2 * NP * BN * 16; }
+template <int BM, int NP>
+constexpr int split_x_bytes() { return split_xpo<BM>() * NP * 16; }
+constexpr int kSplitMiscBytes = kMaxTaps * 16 + 96 + 32 + 64;
+template <int BN, int BM, int NP>
+constexpr int split_lds_bytes() { return 2 * (split_w_bytes<BN, NP>() + split_x_bytes<BM, NP>()) + kSplitMiscBytes; }
+
+// fp32 -> bf16 pieces by truncation, as fp32 bit patterns whose upper halves are the pieces
+__device__ __forceinline__ void split_pieces(float v, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = __float_as_uint(v) & 0xFFFF0000u;
+  const float r = __fsub_rn(v, __uint_as_float(h));  // exact
+  m = __float_as_uint(r) & 0xFFFF0000u;
+  l = __float_as_uint(__fsub_rn(r, __uint_as_float(m)));  // exact; <= 8 significant bits: its lower half is zero
+}
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t hi, uint32_t lo) {  // (hi.upper16 << 16) | lo.upper16
+  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+
+// NP: pieces per value (3: exact split, 6 product terms; 2: 3 terms). 4 consumer waves (64 x BM/4 each) + 4 producer waves.
+template <int BN, int BM, int NP>
+__global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
+  static_assert(BN == 64 && (BM == 512 || BM == 256), "tile shapes of this flavour");
+  constexpr int kProducers = 256;
+  constexpr int CWM = 4, WTM = BM / CWM, TN = BN / 32, TM = WTM / 32;
+  constexpr int PB = 16 * NP;  // bytes per (pixel, octet) of the x patch
+  constexpr int W_BYTES = split_w_bytes<BN, NP>(), X_BYTES = split_x_bytes<BM, NP>(), XPO = split_xpo<BM>();
+  constexpr int W_STEP = 2 * NP * BN * 16, W_HALF = NP * BN * 16, W_PIECE = BN * 16;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  char* const wbuf = smem_c;                  // [2][W_BYTES]
+  char* const xbuf = smem_c + 2 * W_BYTES;    // [2][X_BYTES]
+  float* const smem = reinterpret_cast<float*>(smem_c);
+  int4* const taptab = reinterpret_cast<int4*>(smem_c + 2 * (W_BYTES + X_BYTES));
+  double* const red = reinterpret_cast<double*>(smem_c + 2 * (W_BYTES + X_BYTES) + kMaxTaps * 16);
+  int* const misc = reinterpret_cast<int*>(red + 12);
+  int* const eofftab = misc + 8;  // [kSplitSteps][2]: x byte offset of the (octet, tap) entry of (step, lane half)
+  (void)red;
+
+  unsigned long long* const dbg_ = kStamps ? a.dbg : nullptr;  // stage stamps: diagnostic build only (make STAMPS=1)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const int ptid = producer ? tid - 256 : tid;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave & 3;
+
+  int L = xcd_remap(blockIdx.x, a.total_blocks);
+  const int mt = __builtin_amdgcn_readfirstlane(L % a.m_tiles);
+  L /= a.m_tiles;
+  const int s = __builtin_amdgcn_readfirstlane(L % a.S);
+  L /= a.S;
+  const int nt = __builtin_amdgcn_readfirstlane(L % a.n_tiles);
+  const int g = __builtin_amdgcn_readfirstlane(L / a.n_tiles);
+  const int n0 = nt * BN;
+  const bool pix = a.pixel_major != 0;
+  const int t_NI = a.t_NI, t_R = a.t_R, t_Wt = a.t_Wt, RW = t_R * t_Wt, Mt = t_NI * RW;
+  const int bt = __builtin_amdgcn_readfirstlane(mt % a.n_bt), trest = mt / a.n_bt;
+  const int ct = __builtin_amdgcn_readfirstlane(trest % a.n_ct), rt = __builtin_amdgcn_readfirstlane(trest / a.n_ct);
+  const int b0 = bt * t_NI, r0 = rt * t_R, w0 = ct * t_Wt;
+  const uint32_t inv_rw = RW > 1 ? (uint32_t)((0x100000000ull + (unsigned)RW - 1) / (unsigned)RW) : 0u;
+  const uint32_t inv_wt = t_Wt > 1 ? (uint32_t)((0x100000000ull + (unsigned)t_Wt - 1) / (unsigned)t_Wt) : 0u;
+  auto col_decode = [&](int ml, int& b, int& ho, int& wo) -> bool {  // tile column -> output coordinates; false: dead column
+    const int img = RW == 1 ? ml : (int)__umulhi((uint32_t)ml, inv_rw);
+    const int rem = ml - img * RW;
+    const int r = t_Wt == 1 ? rem : (int)__umulhi((uint32_t)rem, inv_wt);
+    b = b0 + img, ho = r0 + r, wo = w0 + (rem - r * t_Wt);
+    return ml < Mt && b < a.B && ho < a.Ho && wo < a.Wo;
+  };
+  const uint32_t sample = a.sample0 + (uint32_t)s;
+  const int T = a.T, Cig = a.Cig;
+
+  RngKey key_w;
+  key_w.seed_lo = a.seed_lo;
+  key_w.seed_hi = a.seed_hi;
+  key_w.call = a.call + (a.call_base ? __builtin_nontemporal_load(a.call_base) : 0u);
+  key_w.layer_tensor = layer_tensor_word(a.layer_id, 0);
+
+  // ---- active taps of this tile + their window (wave 0), as in the fast kernel -----------------------------------------
+  if (wave == 0) {
+    bool act = false;
+    int4 e = make_int4(0, 0, 0, 0);
+    if (lane < T) {
+      const int kh = lane / a.KW, kw = lane - kh * a.KW;
+      e = make_int4(0, kh * a.DH, kw * a.DW, lane);
+      if (pix) {
+        act = (unsigned)(r0 * a.SH - a.PH + e.y) < (unsigned)a.H && (unsigned)(w0 * a.SW - a.PW + e.z) < (unsigned)a.W;
+      } else {
+        const int lo_h = a.PH - e.y, lo_w = a.PW - e.z;
+        const int hc = lo_h > 0 ? (lo_h + a.SH - 1) / a.SH : 0, wc = lo_w > 0 ? (lo_w + a.SW - 1) / a.SW : 0;
+        act = hc < a.Ho && hc * a.SH - lo_h < a.H && wc < a.Wo && wc * a.SW - lo_w < a.W;
+      }
+    }
+    const unsigned long long mask = __ballot(act);
+    if (act) taptab[__popcll(mask & ((1ull << lane) - 1ull))] = e;
+    int dy0 = act ? e.y : (1 << 20), dy1 = act ? e.y : -1, dx0 = act ? e.z : (1 << 20), dx1 = act ? e.z : -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      dy0 = min(dy0, __shfl_xor(dy0, o, 64)), dy1 = max(dy1, __shfl_xor(dy1, o, 64));
+      dx0 = min(dx0, __shfl_xor(dx0, o, 64)), dx1 = max(dx1, __shfl_xor(dx1, o, 64));
+    }
+    if (lane == 0) misc[0] = __popcll(mask), misc[2] = dy0, misc[3] = dy1, misc[4] = dx0, misc[5] = dx1;
+  }
+  __syncthreads();
+  const int nA = __builtin_amdgcn_readfirstlane(misc[0]);  // 0: degenerate geometry, outputs are the bias alone
+
+  // ---- stage shape ------------------------------------------------------------------------------------------------------
+  // nA > 1: SPO = ceil(nA/2) steps per octet, NO octets per stage. nA == 1: one step per PAIR of octets.
+  const int G8 = Cig >> 3;  // host: Cig % 8 == 0
+  const int dymin = __builtin_amdgcn_readfirstlane(misc[2]), dymax = __builtin_amdgcn_readfirstlane(misc[3]);
+  const int dxmin = __builtin_amdgcn_readfirstlane(misc[4]), dxmax = __builtin_amdgcn_readfirstlane(misc[5]);
+  const int ps_h = (dymax == dymin) ? 1 : a.SH, gs_h = (dymax == dymin) ? a.SH : 1;
+  const int ps_w = (dxmax == dxmin) ? 1 : a.SW, gs_w = (dxmax == dxmin) ? a.SW : 1;
+  const int PHt = (t_R - 1) * ps_h + (dymax - dymin) + 1, PWt = (t_Wt - 1) * ps_w + (dxmax - dxmin) + 1;
+  const int PIMG = PHt * PWt, PCH = t_NI * PIMG;  // patch pixels of one image / of one octet plane (host: PCH <= XPO)
+  const int x_lo = w0 * a.SW - a.PW + dxmin, y_lo = r0 * a.SH - a.PH + dymin;
+  const int SPO = (nA + 1) >> 1;
+  int NO;
+  if (nA <= 1) {
+    NO = 2 * kSplitSteps;
+  } else {
+    NO = kSplitSteps / SPO;
+  }
+  while (NO > 1 && NO * PCH > XPO) --NO;
+  if (nA <= 1 && NO > 1) NO &= ~1;  // whole pairs per stage
+  if (NO > G8) NO = G8;             // (a single stage may then end in a half-empty pair: the W slot holds zeros)
+  const int NQ = NO * (nA > 0 ? nA : 1);                       // (octet, tap) entries of a full stage
+  const int NSTEP = nA <= 1 ? (NO + 1) >> 1 : NO * SPO;        // MFMA steps of a full stage
+  const int NS = nA ? (G8 + NO - 1) / NO : 0;
+  if (tid < 2 * kSplitSteps) {  // entry offsets (bytes into an x buffer) per (step, lane half)
+    const int st_ = tid >> 1, hf = tid & 1;
+    int off = 0;  // dead entries read entry 0 (valid data) against zero weights
+    if (nA == 1) {
+      const int ol = 2 * st_ + hf;
+      if (ol < NO) off = ol * PCH * PB + ((taptab[0].y - dymin) * PWt + (taptab[0].z - dxmin)) * PB;
+    } else if (nA > 1) {
+      const int ol = st_ / SPO, ai = 2 * (st_ - ol * SPO) + hf;
+      if (ol < NO && ai < nA) off = ol * PCH * PB + ((taptab[ai].y - dymin) * PWt + (taptab[ai].z - dxmin)) * PB;
+      else if (ol < NO) off = ol * PCH * PB + ((taptab[0].y - dymin) * PWt + (taptab[0].z - dxmin)) * PB;
+    }
+    eofftab[tid] = off;
+  }
+  // The W slots no unit ever writes (second half of an odd tap count's last step) must hold zeros, and an x entry that is
+  // multiplied by such zeros (or by the zero weights of octets past the end) must at least be finite: clear everything once.
+  for (int i = tid; i < 2 * (W_BYTES + X_BYTES) / 16; i += 512) reinterpret_cast<uint4*>(smem_c)[i] = make_uint4(0, 0, 0, 0);
+
+  const float* const xs = a.x + (long long)s * a.x_sample_stride;
+  constexpr uint32_t kOOB = 0x80000000u;
+  const int Cig4 = Cig;  // a multiple of 8 here
+  const int pk_bytes = a.Co * T * Cig4 * 4;
+  const __amdgpu_buffer_rsrc_t r_mu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mu_pk), 0, pk_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sig_pk), 0, pk_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs), 0, (int)(a.x_elems * 4), 0x00020000);
+  auto ldf = [](const __amdgpu_buffer_rsrc_t& r, uint32_t byte_off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0)); };
+  auto ldf4 = [](const __amdgpu_buffer_rsrc_t& r, uint32_t byte_off) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0)); };
+
+  float* const bias0 = smem;
+  float* const osc = smem + 2 * BN;
+  float* const osh = smem + 3 * BN;
+  const bool kl_block = a.do_kl && (int)blockIdx.x < a.kl_slices;
+  float* const out_s = a.out + (long long)s * a.out_elems;
+  const float* const res_s = a.ep_res ? a.ep_res + (long long)s * a.ep_res_stride : nullptr;
+  const bool relu = a.ep_relu != 0;
+  __syncthreads();  // eofftab, cleared W buffers
+
+  // Read-out of one staged pass of the output tile by all 8 waves (see the output stage below).
+  auto readout_quads = [&](int i, int t0) {
+    constexpr int SROW = BM + 4, SROWS = 32, QROW = BM / 4, NQD = SROWS * QROW, NT_ = 512;
+    constexpr int NITc = (NQD + NT_ - 1) / NT_, U = NITc < 8 ? NITc : 8;
+    const float* const stage = smem + 4 * BN;
+    for (int c0q = t0; c0q < NQD; c0q += NT_ * U) {
+      uint32_t oidx[U];
+      bool okq[U];
+      float4 v[U], r4[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int cr = c0q + NT_ * u, c = cr < NQD ? cr : 0;
+        const int row = c / QROW, m4 = c - row * QROW;
+        int bq, hq, wq;
+        const bool mok = col_decode(4 * m4, bq, hq, wq);
+        const int co_l = i * 32 + row;
+        okq[u] = cr < NQD && mok && n0 + co_l < a.Cog;
+        oidx[u] = okq[u] ? (uint32_t)(((bq * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hq) * a.Wo + wq) : 0u;
+        v[u] = *reinterpret_cast<const float4*>(stage + row * SROW + 4 * m4);
+      }
+      if (res_s) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) r4[u] = *reinterpret_cast<const float4*>(res_s + oidx[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          v[u].x = __fadd_rn(v[u].x, r4[u].x), v[u].y = __fadd_rn(v[u].y, r4[u].y), v[u].z = __fadd_rn(v[u].z, r4[u].z), v[u].w = __fadd_rn(v[u].w, r4[u].w);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (relu) v[u].x = v[u].x < 0.f ? 0.f : v[u].x, v[u].y = v[u].y < 0.f ? 0.f : v[u].y, v[u].z = v[u].z < 0.f ? 0.f : v[u].z, v[u].w = v[u].w < 0.f ? 0.f : v[u].w;
+        if (okq[u]) *reinterpret_cast<float4*>(out_s + oidx[u]) = v[u];
+      }
+    }
+  };
+
+  if (producer) {
+    __builtin_amdgcn_s_setprio(3);
+    // =================================================== PRODUCERS ===========================================================
+    // Weight unit u = (channel quad cq of the octet, row n, entry q = (octet ol, tap slot ai)): 4 sampled weights = one Philox
+    // block. u = ptid + 256 i -> cq = u & 1, n = (u >> 1) % BN, q = (u >> 1) / BN: consecutive lanes fill one 16-byte LDS slot
+    // in pairs and consecutive rows, so the ds_write_b64 of a wave touch every bank once.
+    constexpr int UMAX = (2 * BN * 2 * kSplitSteps + kProducers - 1) / kProducers;
+    const int nunits = 2 * BN * NQ;
+    uint32_t e_off[UMAX];  // draw index (== element offset in the packed tensors) of the unit at octet 0 of stage 0
+    int l_off[UMAX];       // LDS byte offset inside a W buffer; -1: no slot
+    int u_ol[UMAX];        // octet inside the stage
+    const uint32_t inv_na = nA > 1 ? (uint32_t)((0x100000000ull + (unsigned)nA - 1) / (unsigned)nA) : 0u;
+#pragma unroll
+    for (int i = 0; i < UMAX; ++i) {
+      const int u = ptid + kProducers * i;
+      const int uu = u < nunits ? u : 0;
+      const int cq = uu & 1, n = (uu >> 1) & (BN - 1), q = (uu >> 1) / BN;
+      const int ol = nA > 1 ? (int)__umulhi((uint32_t)q, inv_na) : q;
+      const int ai = nA > 1 ? q - ol * nA : 0;
+      const int tap = nA ? taptab[ai].w : 0;
+      const int st_ = nA > 1 ? ol * SPO + (ai >> 1) : (ol >> 1), hf = nA > 1 ? (ai & 1) : (ol & 1);
+      const int co_g = n0 + n;
+      const bool rv = co_g < a.Cog;
+      const uint32_t co = (uint32_t)(g * a.Cog + (rv ? co_g : 0));
+      e_off[i] = rv ? (co * (uint32_t)T + (uint32_t)tap) * (uint32_t)Cig4 + (uint32_t)(8 * ol + 4 * cq) : (kOOB >> 2);
+      l_off[i] = u < nunits ? st_ * W_STEP + hf * W_HALF + n * 16 + cq * 8 : -1;
+      u_ol[i] = ol;
+    }
+    const int wave_u0 = __builtin_amdgcn_readfirstlane(ptid & ~63);
+    // x patch: this thread owns patch pixels ptid + 256 i of every octet plane
+    constexpr int PPOS = (XPO + kProducers - 1) / kProducers;
+    int p_off[PPOS];
+    {
+      const uint32_t inv_pimg = (uint32_t)((0x100000000ull + (unsigned)PIMG - 1) / (unsigned)PIMG);
+      const uint32_t inv_pw = (uint32_t)((0x100000000ull + (unsigned)PWt - 1) / (unsigned)PWt);
+#pragma unroll
+      for (int i = 0; i < PPOS; ++i) {
+        const int pos = ptid + kProducers * i;
+        const int pp = pos < PCH ? pos : 0;
+        const int img = PIMG == 1 ? pp : (int)__umulhi((uint32_t)pp, inv_pimg);
+        const int rem = pp - img * PIMG;
+        const int yy = PWt == 1 ? rem : (int)__umulhi((uint32_t)rem, inv_pw);
+        const int xx = rem - yy * PWt;
+        const int b = b0 + img, y = y_lo + yy * gs_h, x = x_lo + xx * gs_w;
+        const bool ok = pos < PCH && b < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        p_off[i] = ok ? 4 * ((b * a.Ci + g * Cig) * a.HW + y * a.W + x) : (int)kOOB;  // bytes; halo / outside the tile: reads 0
+      }
+    }
+    const int HWb = 4 * a.HW;
+
+    // One stage = loads (issued one stage AHEAD, into registers that the previous stage has just consumed) -> draws (pure
+    // ALU: they run while the loads are in flight) -> sampled weights -> pieces -> LDS -> activations -> pieces -> LDS.
+    float4 mu[UMAX], rs[UMAX];
+    float xv[PPOS][8];  // (staged one octet at a time; the prefetch covers octet 0 of the next stage)
+    auto load_w = [&](int st) {
+      const int oct0 = st * NO;
+#pragma unroll
+      for (int i = 0; i < UMAX; ++i) {
+        if (i == 0 || wave_u0 + kProducers * i < nunits) {  // wave-uniform
+          const bool in = l_off[i] >= 0 && oct0 + u_ol[i] < G8 && e_off[i] != (kOOB >> 2);
+          const uint32_t sb = in ? 4u * (e_off[i] + (uint32_t)(8 * oct0)) : kOOB;
+          mu[i] = ldf4(r_mu, sb), rs[i] = ldf4(r_rs, sb);
+        }
+      }
+    };
+    auto load_x = [&](int oc) {  // the 8 channels of octet oc at this thread's patch pixels
+      const int cb = 8 * oc * HWb;
+#pragma unroll
+      for (int i = 0; i < PPOS; ++i) {
+        if (kProducers * i < PCH) {  // uniform
+#pragma unroll
+          for (int c = 0; c < 8; ++c) xv[i][c] = ldf(r_x, p_off[i] == (int)kOOB ? kOOB : (uint32_t)(p_off[i] + cb + c * HWb));
+        }
+      }
+    };
+    auto store_x = [&](char* Xt, int ol) {
+#pragma unroll
+      for (int i = 0; i < PPOS; ++i) {
+        const int pos = ptid + kProducers * i;
+        if (kProducers * i < PCH && pos < PCH) {
+          uint32_t ph[8], pm[8], pl[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) split_pieces(xv[i][c], ph[c], pm[c], pl[c]);
+          char* const dst = Xt + (ol * PCH + pos) * PB;
+          *reinterpret_cast<uint4*>(dst) = make_uint4(pack_hi16(ph[1], ph[0]), pack_hi16(ph[3], ph[2]), pack_hi16(ph[5], ph[4]), pack_hi16(ph[7], ph[6]));
+          *reinterpret_cast<uint4*>(dst + 16) = make_uint4(pack_hi16(pm[1], pm[0]), pack_hi16(pm[3], pm[2]), pack_hi16(pm[5], pm[4]), pack_hi16(pm[7], pm[6]));
+          if constexpr (NP == 3)
+            *reinterpret_cast<uint4*>(dst + 32) = make_uint4(pack_hi16(pl[1], pl[0]), pack_hi16(pl[3], pl[2]), pack_hi16(pl[5], pl[4]), pack_hi16(pl[7], pl[6]));
+        }
+      }
+    };
+    if (NS > 0) load_w(0), load_x(0);
+    const bool pstamp = dbg_ && blockIdx.x == 0 && tid == 256;
+    for (int st = 0; st <= NS; ++st) {  // NS + 1 barriers, like the consumer arm
+      if (pstamp && st < 60) dbg_[128 + 2 * st] = __builtin_amdgcn_s_memtime();
+      if (pstamp && st == 3) dbg_[250] = dbg_[251] = __builtin_amdgcn_s_memtime();
+      if (st < NS) {
+        char* const Wt = wbuf + (st & 1) * W_BYTES;
+        char* const Xt = xbuf + (st & 1) * X_BYTES;
+        const int oct0 = st * NO;  // first octet of this stage
+        // ---- draws (no load feeds them) ----
+        float ep[UMAX][4];
+#pragma unroll
+        for (int i = 0; i < UMAX; ++i)
+          if (i == 0 || wave_u0 + kProducers * i < nunits)  // wave-uniform
+            philox_normal4(key_w, sample, (e_off[i] + (uint32_t)(8 * oct0)) >> 2, ep[i]);
+        if (pstamp && st == 3) dbg_[252] = __builtin_amdgcn_s_memtime();
+        // ---- sampled weights -> pieces -> LDS ----
+#pragma unroll
+        for (int i = 0; i < UMAX; ++i) {
+          if (i == 0 || wave_u0 + kProducers * i < nunits) {  // wave-uniform
+            const float m4[4] = {mu[i].x, mu[i].y, mu[i].z, mu[i].w}, s4[4] = {rs[i].x, rs[i].y, rs[i].z, rs[i].w};
+            uint32_t wh[4], wm_[4], wl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)  // masked units loaded zeros: w = 0 + 0 * eps = 0
+              split_pieces(__fadd_rn(m4[j], __fmul_rn(s4[j], ep[i][j])), wh[j], wm_[j], wl[j]);
+            if (l_off[i] >= 0) {
+              char* const dst = Wt + l_off[i];
+              *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(wh[1], wh[0]), pack_hi16(wh[3], wh[2]));
+              *reinterpret_cast<uint2*>(dst + W_PIECE) = make_uint2(pack_hi16(wm_[1], wm_[0]), pack_hi16(wm_[3], wm_[2]));
+              if constexpr (NP == 3) *reinterpret_cast<uint2*>(dst + 2 * W_PIECE) = make_uint2(pack_hi16(wl[1], wl[0]), pack_hi16(wl[3], wl[2]));
+            }
+          }
+        }
+        if (pstamp && st == 3) dbg_[253] = __builtin_amdgcn_s_memtime();
+        // ---- activations: NO octets x PPOS pixels x 8 channels, split on the way to LDS ----
+        for (int ol = 0; ol < NO; ++ol) {
+          if (oct0 + ol < G8) store_x(Xt, ol);  // uniform
+          int nxt = oct0 + ol + 1;               // next octet of this stage, or octet 0 of the next stage
+          if (ol + 1 == NO) nxt = (st + 1 < NS) ? oct0 + NO : G8;
+          if (nxt < G8) load_x(nxt);
+        }
+        if (st + 1 < NS) load_w(st + 1);  // (after the x stores: their wait must not cover these loads)
+      }
+      if (pstamp && st < 60) dbg_[128 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
+      __syncthreads();
+    }
+    // bias draw + output-stage constants of this workgroup's channels
+    if (ptid < BN) {
+      float bv = 0.f;
+      const int co_g = n0 + ptid;
+      if (a.mu_b && co_g < a.Cog) {
+        const int co = g * a.Cog + co_g;
+        RngKey kb = key_w;
+        kb.layer_tensor = layer_tensor_word(a.layer_id, 1);
+        float z[4];
+        philox_normal4(kb, sample, (uint32_t)(co >> 2), z);
+        const int sel = co & 3;
+        const float e = sel == 0 ? z[0] : sel == 1 ? z[1] : sel == 2 ? z[2] : z[3];
+        bv = __fadd_rn(a.mu_b[co], __fmul_rn(softplus(a.rho_b[co]), e));
+      }
+      bias0[ptid] = bv;
+      const bool cv = a.ep_scale && co_g < a.Cog;
+      const int cs = cv ? g * a.Cog + co_g : 0;
+      const float sc = a.ep_scale ? a.ep_scale[cs] : 1.f, sh = a.ep_shift ? a.ep_shift[cs] : 0.f;
+      osc[ptid] = cv ? sc : 1.f;
+      osh[ptid] = cv ? sh : 0.f;
+    }
+    __syncthreads();
+    if (a.out_vec4) {  // the consumers pass the output tile through LDS: same barriers and a share of the read-out
+      __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        if (i > 0) __syncthreads();
+        __syncthreads();
+        readout_quads(i, tid);
+      }
+    }
+  } else {
+    // =================================================== CONSUMERS ===========================================================
+    if (kl_block) {  // KL sweep of this workgroup's slice, published before any output is written (see bt_fused_fast.h)
+      long long chunk = (a.w_elems + a.kl_slices - 1) / a.kl_slices;
+      chunk = (chunk + 3) & ~3ll;
+      const long long lo = (long long)blockIdx.x * chunk;
+      const long long hi = (lo + chunk < a.w_elems) ? lo + chunk : a.w_elems;
+      const bool v4 = ((((uintptr_t)a.mu_w | (uintptr_t)a.rho_w | (uintptr_t)a.pmu_w | (uintptr_t)a.psig_w) & 15u) == 0);
+      double kl_acc = 0.0;
+      long long i = lo + 4ll * ptid;
+      if (v4) {
+        for (; i + 3 < hi; i += 1024) {
+          const float4 m4 = *reinterpret_cast<const float4*>(a.mu_w + i), r4 = *reinterpret_cast<const float4*>(a.rho_w + i);
+          const float4 p4 = *reinterpret_cast<const float4*>(a.pmu_w + i), q4 = *reinterpret_cast<const float4*>(a.psig_w + i);
+          const float t0 = kl_term(m4.x, softplus(r4.x), p4.x, q4.x) + kl_term(m4.y, softplus(r4.y), p4.y, q4.y);
+          const float t1 = kl_term(m4.z, softplus(r4.z), p4.z, q4.z) + kl_term(m4.w, softplus(r4.w), p4.w, q4.w);
+          kl_acc += (double)t0 + (double)t1;
+        }
+      }
+      for (; i < hi; i += 1024)
+        for (int j = 0; j < 4; ++j)
+          if (i + j < hi) kl_acc += (double)kl_term(a.mu_w[i + j], softplus(a.rho_w[i + j]), a.pmu_w[i + j], a.psig_w[i + j]);
+      const double wsum = wave_sum(kl_acc);
+      const int nslots = 4 * a.kl_slices;
+      int last = 0;
+      if (lane == 0) last = publish_and_ticket(a.slots, a.counter, (int)blockIdx.x * 4 + wave, wsum, (unsigned)nslots) ? 1 : 0;
+      if (__builtin_amdgcn_readfirstlane(last)) {
+        double t = 0.0;
+        for (int q = lane; q < nslots; q += 64) t += __hip_atomic_load(&a.slots[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = wave_sum(t);
+        double bt_ = 0.0;
+        if (a.mu_b)
+          for (int c = lane; c < a.Co; c += 64) bt_ += (double)kl_term(a.mu_b[c], softplus(a.rho_b[c]), a.pmu_b[c], a.psig_b[c]);
+        bt_ = wave_sum(bt_);
+        if (lane == 0) {
+          float kl = (float)(t / (double)a.w_elems);
+          if (a.mu_b) kl += (float)(bt_ / (double)a.Co);
+          a.kl_out[0] = kl;
+          __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    // x byte offset of this lane's output pixel per 32-wide column group, and of the entries of this lane half
+    int colb[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int ml = wm * WTM + j * 32 + li;
+      int b, ho, wo;
+      const bool live = col_decode(ml, b, ho, wo);
+      colb[j] = live ? ((b - b0) * PIMG + (ho - r0) * ps_h * PWt + (wo - w0) * ps_w) * PB : 0;
+    }
+    int eoff[kSplitSteps];
+#pragma unroll
+    for (int q = 0; q < kSplitSteps; ++q) eoff[q] = eofftab[2 * q + lh];
+    const int wlane = lh * W_HALF + li * 16;
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool cstamp = dbg_ && blockIdx.x == 0 && tid == 0;
+    __syncthreads();  // stage 0 staged
+    if (cstamp) dbg_[0] = __builtin_amdgcn_s_memtime();
+    for (int st = 0; st < NS; ++st) {
+      if (cstamp && st < 60) dbg_[2 + 2 * st] = __builtin_amdgcn_s_memtime();
+      const char* const Wt = wbuf + (st & 1) * W_BYTES + wlane;
+      const char* const Xt = xbuf + (st & 1) * X_BYTES;
+      int nstep = NSTEP;  // the last stage may hold fewer octets
+      if ((st + 1) * NO > G8) {
+        const int no_l = G8 - st * NO;
+        nstep = nA <= 1 ? (no_l + 1) >> 1 : no_l * SPO;
+      }
+#pragma unroll
+      for (int q = 0; q < kSplitSteps; ++q) {
+        if (q < nstep) {  // uniform
+          bf16x8 wf[TN][NP];
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) wf[i][p] = *reinterpret_cast<const bf16x8*>(Wt + q * W_STEP + p * W_PIECE + i * 32 * 16);
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            const char* const px = Xt + colb[j] + eoff[q];
+            bf16x8 xf[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(px + 16 * p);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+              // D[pixel][channel]: x is the A operand, W the B operand; terms in decreasing weight
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[i][0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[i][1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], wf[i][0], acc[i][j], 0, 0, 0);
+              if constexpr (NP == 3) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[i][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], wf[i][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[2], wf[i][0], acc[i][j], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      if (cstamp && st < 60) dbg_[2 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
+      __syncthreads();
+    }
+    if (cstamp) dbg_[1] = __builtin_amdgcn_s_memtime();
+    __syncthreads();  // the producers have staged bias / output-stage constants
+
+    // ---- output stage + store (bt_fused_fast.h: lane = one channel, registers 4q..4q+3 = 4 consecutive positions) ----
+    if (a.out_vec4) {
+      constexpr int SROW = BM + 4, SROWS = 32;
+      static_assert((4 * BN + SROWS * SROW) * 4 <= 2 * (W_BYTES + X_BYTES), "output staging fits the operand buffers");
+      float* const stage = smem + 4 * BN;
+      float bsv[TN], scv[TN], shv[TN];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int co_l = i * 32 + li;
+        bsv[i] = bias0[co_l], scv[i] = osc[co_l], shv[i] = osh[co_l];
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        if (i > 0) __syncthreads();  // the previous pass has been read out
+        float* const srow = stage + li * SROW + wm * WTM + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(__fmul_rn(__fadd_rn(acc[i][j][4 * q + e], bsv[i]), scv[i]), shv[i]);
+            *reinterpret_cast<float4*>(srow + j * 32 + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+        __syncthreads();
+        readout_quads(i, tid);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int co_l = i * 32 + li;
+          const bool cok = n0 + co_l < a.Cog;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            int bb, hh, ww;
+            const bool live = col_decode(wm * WTM + j * 32 + row, bb, hh, ww);
+            if (live && cok) {
+              const uint32_t oi = (uint32_t)(((bb * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hh) * a.Wo + ww);
+              float v = __fadd_rn(acc[i][j][r], bias0[co_l]);
+              v = __fadd_rn(__fmul_rn(v, osc[co_l]), osh[co_l]);
+              if (res_s) v = __fadd_rn(v, res_s[oi]);
+              v = (relu && v < 0.f) ? 0.f : v;
+              out_s[oi] = v;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (dbg_ && blockIdx.x == 0 && tid == 0) dbg_[126] = __builtin_amdgcn_s_memtime();
+}
+
+}  // namespace bt

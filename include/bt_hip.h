@@ -193,6 +193,14 @@ int bt_rng_normal_fill(const bt_rng *rng, uint32_t tensor_id, int32_t S, int64_t
 int bt_rng_sign_fill(const bt_rng *rng, uint32_t tensor_id, int32_t S, int64_t n, float *out, bt_stream_t stream);
 int bt_rng_philox_raw(uint64_t seed, const uint32_t ctr[4], uint32_t out_host[4]); /* host-side Philox4x32-10 KAT hook */
 
+/* Contraction arithmetic of the fused forwards (process-wide; default from env BT_CONTRACTION = f32 | bf16x3 | bf16x2):
+ *   0  automatic: wherever a launch is eligible, every fp32 operand is cut into three bf16 pieces (an EXACT split of the
+ *      24-bit significand) and the product runs as the 6 piece products of weight >= 2^-16 on the bf16 matrix pipe with
+ *      fp32 accumulation -- fp32-level accuracy at 6/16 of the fp32-MFMA time; other launches use fp32 MFMA;
+ *   1  fp32 MFMA everywhere (the bit-exact fp32 FMA chain of round 1);
+ *   2  two pieces, 3 product terms (relative error ~1e-5 per product): opt-in. */
+int bt_set_contraction(int mode);
+
 /* MC epilogue (examples/main_bayesian_cifar_dnn2bnn.py:551-557 and :402-412): from logits [S][B][C]
  * accumulate into packed[B*C + B + B*C] = [sum_s softmax | sum_s entropy | sum_s logits] (overwrites). */
 int bt_mc_epilogue(int32_t S, int32_t B, int32_t C, const float *logits, float *packed, bt_stream_t stream);

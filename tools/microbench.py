@@ -20,9 +20,12 @@ ap.add_argument("--flip", action="store_true")
 ap.add_argument("--kl", action="store_true")
 ap.add_argument("--shared", action="store_true")
 ap.add_argument("--sigma", action="store_true")
+ap.add_argument("--mode", type=int, default=0, help="bt_set_contraction: 0 auto (bf16x3 split), 1 fp32 MFMA, 2 bf16x2")
 a = ap.parse_args()
 Ci, Co, k, st, pd, H = SHAPES[a.shape]
 dev = torch.device("cuda")
+from bayesian_torch_amd import _lib
+_lib.check(_lib.lib().bt_set_contraction(a.mode))
 torch.manual_seed(0)
 mu = (torch.randn(Co, Ci, k, k, device=dev) * 0.1)
 rho = (torch.randn(Co, Ci, k, k, device=dev) * 0.1 - 3)
@@ -44,4 +47,4 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
 Ho = out.shape[-1]
 fl = 2.0 * a.S * a.B * Co * Ho * Ho * Ci * k * k * (2 if a.flip else 1)
-print(f"{a.shape} S={a.S} B={a.B} flip={a.flip} kl={a.kl}: {ms*1e3:.1f} us  {fl/ms/1e9:.2f} TF/s nominal  out={tuple(out.shape)}")
+print(f"{a.shape} S={a.S} B={a.B} flip={a.flip} kl={a.kl} mode={a.mode}: {ms*1e3:.1f} us  {fl/ms/1e9:.2f} TF/s nominal  out={tuple(out.shape)}  {_lib.lib().bt_last_kernel_name().decode()}")

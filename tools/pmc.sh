@@ -16,7 +16,7 @@ tag = sys.argv[1]
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(f"gpurun_out/pmc_{tag}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "fused_f" not in r["Kernel_Name"]:
+        if "fused_" not in r["Kernel_Name"]:
             continue
         k = r["Counter_Name"]
         agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
