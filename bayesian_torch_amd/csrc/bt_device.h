@@ -165,6 +165,18 @@ __device__ __forceinline__ bool publish_and_ticket(double* slots, unsigned* coun
   return true;
 }
 
+// The same hand-off without any fence: the partial goes out as an agent-scope (sc1, write-through) 8-byte store, the storing lane
+// drains it (vmcnt(0)) before its agent-scope ticket add, and the last arriver -- told by the value its own add returned -- reads
+// the slots with agent-scope (sc1) loads, which bypass its L1 (MI355X_MICROARCH.md, "Valid forms", first row of the sc1 table:
+// one unsharded counter, all handed-off bytes stored and loaded sc1). No L2 write-back, so the cost does not depend on how much
+// output other workgroups of the XCD have dirtied by then: the partial can be published at any point of the kernel.
+__device__ __forceinline__ bool publish_and_ticket_wt(double* slots, unsigned* counter, int slot, double v, unsigned expected) {
+  __hip_atomic_store(&slots[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return t == expected - 1u;
+}
+
 // Workspace layout (BT_WORKSPACE_BYTES = 64 KiB, zero-filled by the caller once):
 //   [0, 8)        ticket counter (uint32) + pad
 //   [64, 64+8*N)  double slots, N <= kMaxSlots

@@ -31,8 +31,8 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kSplitSteps = 5;  // MFMA K16-steps per barrier stage (9 taps of one octet = 5 steps)
 
 template <int BM>
-constexpr int split_xpo() {  // pixel-octets one x buffer holds (8 images of a 10x10 patch = 800; 16 of a 6x6 = 576)
-  return BM >= 512 ? 832 : 640;
+constexpr int split_xpo() {  // pixel-octets one x buffer holds (8 images of a 10x10 patch = 800; 16 of a 6x6 = 576): what 160 KB allow
+  return 1024;
 }
 template <int BN, int NP>
 constexpr int split_w_bytes() { return kSplitSteps * 2 * NP * BN * 16; }
@@ -53,11 +53,19 @@ __device__ __forceinline__ uint32_t pack_hi16(uint32_t hi, uint32_t lo) {  // (h
   return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
 }
 
-// NP: pieces per value (3: exact split, 6 product terms; 2: 3 terms). 4 consumer waves (64 x BM/4 each) + 4 producer waves.
-template <int BN, int BM, int NP>
-__global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
-  static_assert(BN == 64 && (BM == 512 || BM == 256), "tile shapes of this flavour");
-  constexpr int kProducers = 256;
+// NP: pieces per value (3: exact split, 6 product terms; 2: 3 terms). 4 consumer waves (64 x BM/4 each) + NPW producer waves
+// (8 on the 128-wide tile of the small feature maps, where one draw serves few columns and the accumulators are small).
+// XM: how the x patch is fetched. A producer thread owns ITEMS f = ptid + kProducers i of the stage's NO octet planes (the same
+// ones in every stage, so their addresses are decoded once) and issues all their loads one stage ahead.
+//   0: item = (patch pixel, octet): one dword per channel; any geometry.
+//   1: 1x1 input planes (and Linear): item = (image, octet), its 8 channels are 32 contiguous bytes.
+//   2: 2x2 input planes wholly inside the patch: item = (image, octet), a channel's plane is 16 contiguous bytes.
+//   3: stride-1 tiles of whole rows with W % 4 == 0: item = (4 consecutive input pixels, half an octet): 16-byte row pieces;
+//      the zero halo of the patch is never written (the buffers are cleared once).
+template <int BN, int BM, int NP, int NPW, int XM>
+__global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdArgs a) {
+  static_assert(BN == 64 && (BM == 512 || BM == 256 || BM == 128), "tile shapes of this flavour");
+  constexpr int kProducers = 64 * NPW, kThreadsAll = 256 + kProducers;
   constexpr int CWM = 4, WTM = BM / CWM, TN = BN / 32, TM = WTM / 32;
   constexpr int PB = 16 * NP;  // bytes per (pixel, octet) of the x patch
   constexpr int W_BYTES = split_w_bytes<BN, NP>(), X_BYTES = split_x_bytes<BM, NP>(), XPO = split_xpo<BM>();
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
   }
   // The W slots no unit ever writes (second half of an odd tap count's last step) must hold zeros, and an x entry that is
   // multiplied by such zeros (or by the zero weights of octets past the end) must at least be finite: clear everything once.
-  for (int i = tid; i < 2 * (W_BYTES + X_BYTES) / 16; i += 512) reinterpret_cast<uint4*>(smem_c)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < 2 * (W_BYTES + X_BYTES) / 16; i += kThreadsAll) reinterpret_cast<uint4*>(smem_c)[i] = make_uint4(0, 0, 0, 0);
 
   const float* const xs = a.x + (long long)s * a.x_sample_stride;
   constexpr uint32_t kOOB = 0x80000000u;
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
 
   // Read-out of one staged pass of the output tile by all 8 waves (see the output stage below).
   auto readout_quads = [&](int i, int t0) {
-    constexpr int SROW = BM + 4, SROWS = 32, QROW = BM / 4, NQD = SROWS * QROW, NT_ = 512;
+    constexpr int SROW = BM + 4, SROWS = 32, QROW = BM / 4, NQD = SROWS * QROW, NT_ = kThreadsAll;
     constexpr int NITc = (NQD + NT_ - 1) / NT_, U = NITc < 8 ? NITc : 8;
     const float* const stage = smem + 4 * BN;
     for (int c0q = t0; c0q < NQD; c0q += NT_ * U) {
@@ -249,7 +257,13 @@ __global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
     for (int i = 0; i < UMAX; ++i) {
       const int u = ptid + kProducers * i;
       const int uu = u < nunits ? u : 0;
-      const int cq = uu & 1, n = (uu >> 1) & (BN - 1), q = (uu >> 1) / BN;
+      int cq = uu & 1, n = (uu >> 1) & (BN - 1), q = (uu >> 1) / BN;
+      if (nA == 1 && NO > 1) {  // one tap: a row's octets are contiguous in the packed tensors -> (quad, octet) fastest
+        const uint32_t inv_no = (uint32_t)((0x100000000ull + (unsigned)NO - 1) / (unsigned)NO);
+        const int t2 = uu >> 1;
+        n = (int)__umulhi((uint32_t)t2, inv_no);
+        q = t2 - n * NO;
+      }
       const int ol = nA > 1 ? (int)__umulhi((uint32_t)q, inv_na) : q;
       const int ai = nA > 1 ? q - ol * nA : 0;
       const int tap = nA ? taptab[ai].w : 0;
@@ -258,35 +272,80 @@ __global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
       const bool rv = co_g < a.Cog;
       const uint32_t co = (uint32_t)(g * a.Cog + (rv ? co_g : 0));
       e_off[i] = rv ? (co * (uint32_t)T + (uint32_t)tap) * (uint32_t)Cig4 + (uint32_t)(8 * ol + 4 * cq) : (kOOB >> 2);
-      l_off[i] = u < nunits ? st_ * W_STEP + hf * W_HALF + n * 16 + cq * 8 : -1;
+      // (row slots are XOR-swizzled with the plane index: the units of one row that land in different (step, half) planes --
+      //  consecutive lanes when one tap is active -- then write different banks; reads stay 16 distinct slots per lane group)
+      l_off[i] = u < nunits ? st_ * W_STEP + hf * W_HALF + (n ^ ((2 * st_ + hf) & 7)) * 16 + cq * 8 : -1;
       u_ol[i] = ol;
     }
     const int wave_u0 = __builtin_amdgcn_readfirstlane(ptid & ~63);
-    // x patch: this thread owns patch pixels ptid + 256 i of every octet plane
-    constexpr int PPOS = (XPO + kProducers - 1) / kProducers;
-    int p_off[PPOS];
+    // x items of this thread (see XM above): global byte offset of the item at octet 0, LDS byte offset inside an x buffer,
+    // octet inside the stage.
+    constexpr int PIT = XM == 2 ? (XPO / 4 + kProducers - 1) / kProducers : XM == 3 ? (XPO / 2 + kProducers - 1) / kProducers : (XPO + kProducers - 1) / kProducers;
+    constexpr int XV = XM == 2 ? 32 : XM == 3 ? 16 : 8;
+    int it_off[PIT], it_lds[PIT], it_ol[PIT];
+    // real input rows of the patch and 16-byte quads per row (XM 3)
+    const int ylo_r = y_lo > 0 ? y_lo : 0, yhi_r = (y_lo + PHt < a.H) ? y_lo + PHt : a.H;
+    const int nyr = yhi_r > ylo_r ? yhi_r - ylo_r : 0, W4 = a.W >> 2;
+    const int per_oct = XM == 2 ? t_NI : XM == 3 ? 2 * t_NI * nyr * W4 : PCH;
+    const int n_items = NO * per_oct;
     {
+      const uint32_t inv_per = per_oct > 1 ? (uint32_t)((0x100000000ull + (unsigned)per_oct - 1) / (unsigned)per_oct) : 0u;
       const uint32_t inv_pimg = (uint32_t)((0x100000000ull + (unsigned)PIMG - 1) / (unsigned)PIMG);
       const uint32_t inv_pw = (uint32_t)((0x100000000ull + (unsigned)PWt - 1) / (unsigned)PWt);
+      const int qpi = nyr * W4;  // quads per image (XM 3)
+      const uint32_t inv_qpi = qpi > 1 ? (uint32_t)((0x100000000ull + (unsigned)qpi - 1) / (unsigned)qpi) : 0u;
+      const uint32_t inv_w4 = W4 > 1 ? (uint32_t)((0x100000000ull + (unsigned)W4 - 1) / (unsigned)W4) : 0u;
 #pragma unroll
-      for (int i = 0; i < PPOS; ++i) {
-        const int pos = ptid + kProducers * i;
-        const int pp = pos < PCH ? pos : 0;
-        const int img = PIMG == 1 ? pp : (int)__umulhi((uint32_t)pp, inv_pimg);
-        const int rem = pp - img * PIMG;
-        const int yy = PWt == 1 ? rem : (int)__umulhi((uint32_t)rem, inv_pw);
-        const int xx = rem - yy * PWt;
-        const int b = b0 + img, y = y_lo + yy * gs_h, x = x_lo + xx * gs_w;
-        const bool ok = pos < PCH && b < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-        p_off[i] = ok ? 4 * ((b * a.Ci + g * Cig) * a.HW + y * a.W + x) : (int)kOOB;  // bytes; halo / outside the tile: reads 0
+      for (int i = 0; i < PIT; ++i) {
+        const int f = ptid + kProducers * i;
+        const int ff = f < n_items ? f : 0;
+        int ol = per_oct <= 1 ? ff : (int)__umulhi((uint32_t)ff, inv_per);
+        int r = ff - ol * per_oct;
+        if constexpr (XM == 1) {  // octet fastest: consecutive lanes read consecutive 32-byte pieces of one image
+          const uint32_t inv_no = NO > 1 ? (uint32_t)((0x100000000ull + (unsigned)NO - 1) / (unsigned)NO) : 0u;
+          r = NO <= 1 ? ff : (int)__umulhi((uint32_t)ff, inv_no);
+          ol = ff - r * NO;
+        }
+        int off = (int)kOOB, lds = -1;
+        if constexpr (XM == 2) {
+          const int b = b0 + r;
+          lds = (ol * PCH + 4 * r) * PB;
+          if (b < a.B) off = 16 * (b * a.Ci + g * Cig);
+        } else if constexpr (XM == 1) {
+          const int b = b0 + r;
+          lds = (ol * PCH + r) * PB;
+          if (b < a.B) off = 4 * (b * a.Ci + g * Cig);
+        } else if constexpr (XM == 3) {
+          const int hc = r & 1, q = r >> 1;
+          const int img = qpi <= 1 ? q : (int)__umulhi((uint32_t)q, inv_qpi);
+          const int rem = q - img * qpi;
+          const int yr = W4 <= 1 ? rem : (int)__umulhi((uint32_t)rem, inv_w4);
+          const int xq = rem - yr * W4;
+          const int b = b0 + img, y = ylo_r + yr, x = 4 * xq;
+          lds = (ol * PCH + img * PIMG + (y - y_lo) * PWt + (x - x_lo)) * PB + hc * 8;
+          if (b < a.B) off = 4 * ((b * a.Ci + g * Cig + 4 * hc) * a.HW + y * a.W + x);
+        } else {
+          const int img = PIMG == 1 ? r : (int)__umulhi((uint32_t)r, inv_pimg);
+          const int rem = r - img * PIMG;
+          const int yy = PWt == 1 ? rem : (int)__umulhi((uint32_t)rem, inv_pw);
+          const int xx = rem - yy * PWt;
+          const int b = b0 + img, y = y_lo + yy * gs_h, x = x_lo + xx * gs_w;
+          lds = (ol * PCH + r) * PB;
+          if (b < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) off = 4 * ((b * a.Ci + g * Cig) * a.HW + y * a.W + x);  // else: halo, reads 0
+        }
+        it_off[i] = off;
+        it_lds[i] = f < n_items ? lds : -1;
+        it_ol[i] = ol;
       }
     }
     const int HWb = 4 * a.HW;
+    const int wave_i0 = wave_u0;  // first item index of this wave (iteration 0)
+    const int n_items_w = n_items;
 
     // One stage = loads (issued one stage AHEAD, into registers that the previous stage has just consumed) -> draws (pure
     // ALU: they run while the loads are in flight) -> sampled weights -> pieces -> LDS -> activations -> pieces -> LDS.
     float4 mu[UMAX], rs[UMAX];
-    float xv[PPOS][8];  // (staged one octet at a time; the prefetch covers octet 0 of the next stage)
+    float xv[PIT][XV];
     auto load_w = [&](int st) {
       const int oct0 = st * NO;
 #pragma unroll
@@ -298,29 +357,69 @@ __global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
         }
       }
     };
-    auto load_x = [&](int oc) {  // the 8 channels of octet oc at this thread's patch pixels
-      const int cb = 8 * oc * HWb;
+    auto load_x = [&](int st) {  // every item of stage st
+      const int oct0 = st * NO;
 #pragma unroll
-      for (int i = 0; i < PPOS; ++i) {
-        if (kProducers * i < PCH) {  // uniform
+      for (int i = 0; i < PIT; ++i) {
+        if (i == 0 || wave_i0 + kProducers * i < n_items_w) {  // wave-uniform
+          const int oc = oct0 + it_ol[i];
+          const bool in = it_off[i] != (int)kOOB && oc < G8;  // octets past the end read zeros (their weights are zeros too)
+          if constexpr (XM == 2) {
 #pragma unroll
-          for (int c = 0; c < 8; ++c) xv[i][c] = ldf(r_x, p_off[i] == (int)kOOB ? kOOB : (uint32_t)(p_off[i] + cb + c * HWb));
+            for (int c = 0; c < 8; ++c) {
+              const float4 v = ldf4(r_x, in ? (uint32_t)(it_off[i] + 16 * (8 * oc + c)) : kOOB);
+              xv[i][4 * c] = v.x, xv[i][4 * c + 1] = v.y, xv[i][4 * c + 2] = v.z, xv[i][4 * c + 3] = v.w;
+            }
+          } else if constexpr (XM == 1) {
+            const float4 v0 = ldf4(r_x, in ? (uint32_t)(it_off[i] + 32 * oc) : kOOB), v1 = ldf4(r_x, in ? (uint32_t)(it_off[i] + 32 * oc + 16) : kOOB);
+            xv[i][0] = v0.x, xv[i][1] = v0.y, xv[i][2] = v0.z, xv[i][3] = v0.w, xv[i][4] = v1.x, xv[i][5] = v1.y, xv[i][6] = v1.z, xv[i][7] = v1.w;
+          } else if constexpr (XM == 3) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float4 v = ldf4(r_x, in ? (uint32_t)(it_off[i] + (8 * oc + c) * HWb) : kOOB);
+              xv[i][4 * c] = v.x, xv[i][4 * c + 1] = v.y, xv[i][4 * c + 2] = v.z, xv[i][4 * c + 3] = v.w;
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xv[i][c] = ldf(r_x, in ? (uint32_t)(it_off[i] + (8 * oc + c) * HWb) : kOOB);
+          }
         }
       }
     };
-    auto store_x = [&](char* Xt, int ol) {
+    auto store_px = [&](char* dst, const float (&v)[8]) {  // 8 channels of one pixel -> NP pieces x 16 bytes
+      uint32_t ph[8], pm[8], pl[8];
 #pragma unroll
-      for (int i = 0; i < PPOS; ++i) {
-        const int pos = ptid + kProducers * i;
-        if (kProducers * i < PCH && pos < PCH) {
-          uint32_t ph[8], pm[8], pl[8];
+      for (int c = 0; c < 8; ++c) split_pieces(v[c], ph[c], pm[c], pl[c]);
+      *reinterpret_cast<uint4*>(dst) = make_uint4(pack_hi16(ph[1], ph[0]), pack_hi16(ph[3], ph[2]), pack_hi16(ph[5], ph[4]), pack_hi16(ph[7], ph[6]));
+      *reinterpret_cast<uint4*>(dst + 16) = make_uint4(pack_hi16(pm[1], pm[0]), pack_hi16(pm[3], pm[2]), pack_hi16(pm[5], pm[4]), pack_hi16(pm[7], pm[6]));
+      if constexpr (NP == 3)
+        *reinterpret_cast<uint4*>(dst + 32) = make_uint4(pack_hi16(pl[1], pl[0]), pack_hi16(pl[3], pl[2]), pack_hi16(pl[5], pl[4]), pack_hi16(pl[7], pl[6]));
+    };
+    auto store_x = [&](char* Xt) {
 #pragma unroll
-          for (int c = 0; c < 8; ++c) split_pieces(xv[i][c], ph[c], pm[c], pl[c]);
-          char* const dst = Xt + (ol * PCH + pos) * PB;
-          *reinterpret_cast<uint4*>(dst) = make_uint4(pack_hi16(ph[1], ph[0]), pack_hi16(ph[3], ph[2]), pack_hi16(ph[5], ph[4]), pack_hi16(ph[7], ph[6]));
-          *reinterpret_cast<uint4*>(dst + 16) = make_uint4(pack_hi16(pm[1], pm[0]), pack_hi16(pm[3], pm[2]), pack_hi16(pm[5], pm[4]), pack_hi16(pm[7], pm[6]));
-          if constexpr (NP == 3)
-            *reinterpret_cast<uint4*>(dst + 32) = make_uint4(pack_hi16(pl[1], pl[0]), pack_hi16(pl[3], pl[2]), pack_hi16(pl[5], pl[4]), pack_hi16(pl[7], pl[6]));
+      for (int i = 0; i < PIT; ++i) {
+        if ((i == 0 || wave_i0 + kProducers * i < n_items_w) && it_lds[i] >= 0) {
+          char* const dst = Xt + it_lds[i];
+          if constexpr (XM == 2) {
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+              const float v[8] = {xv[i][px], xv[i][4 + px], xv[i][8 + px], xv[i][12 + px], xv[i][16 + px], xv[i][20 + px], xv[i][24 + px], xv[i][28 + px]};
+              store_px(dst + px * PB, v);
+            }
+          } else if constexpr (XM == 3) {  // 4 pixels x 4 channels: half of each pixel's 16-byte slots
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+              uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) split_pieces(xv[i][4 * c + px], ph[c], pm[c], pl[c]);
+              *reinterpret_cast<uint2*>(dst + px * PB) = make_uint2(pack_hi16(ph[1], ph[0]), pack_hi16(ph[3], ph[2]));
+              *reinterpret_cast<uint2*>(dst + px * PB + 16) = make_uint2(pack_hi16(pm[1], pm[0]), pack_hi16(pm[3], pm[2]));
+              if constexpr (NP == 3) *reinterpret_cast<uint2*>(dst + px * PB + 32) = make_uint2(pack_hi16(pl[1], pl[0]), pack_hi16(pl[3], pl[2]));
+            }
+          } else {
+            const float v[8] = {xv[i][0], xv[i][1], xv[i][2], xv[i][3], xv[i][4], xv[i][5], xv[i][6], xv[i][7]};
+            store_px(dst, v);
+          }
         }
       }
     };
@@ -358,14 +457,9 @@ __global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
           }
         }
         if (pstamp && st == 3) dbg_[253] = __builtin_amdgcn_s_memtime();
-        // ---- activations: NO octets x PPOS pixels x 8 channels, split on the way to LDS ----
-        for (int ol = 0; ol < NO; ++ol) {
-          if (oct0 + ol < G8) store_x(Xt, ol);  // uniform
-          int nxt = oct0 + ol + 1;               // next octet of this stage, or octet 0 of the next stage
-          if (ol + 1 == NO) nxt = (st + 1 < NS) ? oct0 + NO : G8;
-          if (nxt < G8) load_x(nxt);
-        }
-        if (st + 1 < NS) load_w(st + 1);  // (after the x stores: their wait must not cover these loads)
+        // ---- activations: this thread's items of the stage's NO octet planes, split on the way to LDS ----
+        store_x(Xt);
+        if (st + 1 < NS) load_x(st + 1), load_w(st + 1);  // next stage's loads: in flight across the barrier and the draws
       }
       if (pstamp && st < 60) dbg_[128 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
       __syncthreads();
@@ -403,31 +497,47 @@ __global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
     }
   } else {
     // =================================================== CONSUMERS ===========================================================
-    if (kl_block) {  // KL sweep of this workgroup's slice, published before any output is written (see bt_fused_fast.h)
+    // KL sweep of this workgroup's slice of the flat parameter tensors, one float4 group per thread and K-stage, BEHIND the
+    // stage's MFMAs: in the layers with many parameters the consumers wait for the producers anyway, in the MFMA-bound layers
+    // a slice is a group or two. Same per-thread order of accumulation as one uninterrupted sweep; the partial is published
+    // with write-through stores (publish_and_ticket_wt: no L2 write-back, so publishing late costs nothing extra).
+    long long kl_i = 0, kl_hi = 0;
+    double kl_acc = 0.0;
+    bool kl_v4 = false;
+    if (kl_block) {
       long long chunk = (a.w_elems + a.kl_slices - 1) / a.kl_slices;
       chunk = (chunk + 3) & ~3ll;
       const long long lo = (long long)blockIdx.x * chunk;
-      const long long hi = (lo + chunk < a.w_elems) ? lo + chunk : a.w_elems;
-      const bool v4 = ((((uintptr_t)a.mu_w | (uintptr_t)a.rho_w | (uintptr_t)a.pmu_w | (uintptr_t)a.psig_w) & 15u) == 0);
-      double kl_acc = 0.0;
-      long long i = lo + 4ll * ptid;
-      if (v4) {
-        for (; i + 3 < hi; i += 1024) {
-          const float4 m4 = *reinterpret_cast<const float4*>(a.mu_w + i), r4 = *reinterpret_cast<const float4*>(a.rho_w + i);
-          const float4 p4 = *reinterpret_cast<const float4*>(a.pmu_w + i), q4 = *reinterpret_cast<const float4*>(a.psig_w + i);
-          const float t0 = kl_term(m4.x, softplus(r4.x), p4.x, q4.x) + kl_term(m4.y, softplus(r4.y), p4.y, q4.y);
-          const float t1 = kl_term(m4.z, softplus(r4.z), p4.z, q4.z) + kl_term(m4.w, softplus(r4.w), p4.w, q4.w);
-          kl_acc += (double)t0 + (double)t1;
-        }
-      }
-      for (; i < hi; i += 1024)
+      kl_hi = (lo + chunk < a.w_elems) ? lo + chunk : a.w_elems;
+      kl_v4 = ((((uintptr_t)a.mu_w | (uintptr_t)a.rho_w | (uintptr_t)a.pmu_w | (uintptr_t)a.psig_w) & 15u) == 0);
+      kl_i = lo + 4ll * ptid;
+    }
+    auto kl_group = [&]() {  // -> false when this thread has no whole float4 group left
+      if (!(kl_v4 && kl_i + 3 < kl_hi)) return false;
+      const float4 m4 = *reinterpret_cast<const float4*>(a.mu_w + kl_i), r4 = *reinterpret_cast<const float4*>(a.rho_w + kl_i);
+      const float4 p4 = *reinterpret_cast<const float4*>(a.pmu_w + kl_i), q4 = *reinterpret_cast<const float4*>(a.psig_w + kl_i);
+      const float t0 = kl_term(m4.x, softplus(r4.x), p4.x, q4.x) + kl_term(m4.y, softplus(r4.y), p4.y, q4.y);
+      const float t1 = kl_term(m4.z, softplus(r4.z), p4.z, q4.z) + kl_term(m4.w, softplus(r4.w), p4.w, q4.w);
+      kl_acc += (double)t0 + (double)t1;
+      kl_i += 1024;
+      return true;
+    };
+    auto kl_finish = [&]() {
+      while (kl_group()) {}
+      for (; kl_i < kl_hi; kl_i += 1024)  // tail quad / unaligned bases
         for (int j = 0; j < 4; ++j)
-          if (i + j < hi) kl_acc += (double)kl_term(a.mu_w[i + j], softplus(a.rho_w[i + j]), a.pmu_w[i + j], a.psig_w[i + j]);
+          if (kl_i + j < kl_hi) kl_acc += (double)kl_term(a.mu_w[kl_i + j], softplus(a.rho_w[kl_i + j]), a.pmu_w[kl_i + j], a.psig_w[kl_i + j]);
       const double wsum = wave_sum(kl_acc);
+      // every consumer wave stores its partial write-through and drains the store; the workgroup's ONE ticket is taken by
+      // thread 0 behind the next workgroup barrier (kl_ticket below): 256 adds on the counter instead of 1024
+      if (lane == 0) __hip_atomic_store(&a.slots[(int)blockIdx.x * 4 + wave], wsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto kl_ticket = [&]() {  // thread 0's wave, after the barrier that follows kl_finish in every consumer wave
       const int nslots = 4 * a.kl_slices;
       int last = 0;
-      if (lane == 0) last = publish_and_ticket(a.slots, a.counter, (int)blockIdx.x * 4 + wave, wsum, (unsigned)nslots) ? 1 : 0;
-      if (__builtin_amdgcn_readfirstlane(last)) {
+      if (lane == 0) last = (__hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.kl_slices - 1u) ? 1 : 0;
+      if (__builtin_amdgcn_readfirstlane(last)) {  // this workgroup arrived last: every slot is published
         double t = 0.0;
         for (int q = lane; q < nslots; q += 64) t += __hip_atomic_load(&a.slots[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         t = wave_sum(t);
@@ -439,10 +549,10 @@ __global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
           float kl = (float)(t / (double)a.w_elems);
           if (a.mu_b) kl += (float)(bt_ / (double)a.Co);
           a.kl_out[0] = kl;
-          __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // leave the workspace zeroed
         }
       }
-    }
+    };
     // x byte offset of this lane's output pixel per 32-wide column group, and of the entries of this lane half
     int colb[TM];
 #pragma unroll
@@ -455,7 +565,9 @@ __global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
     int eoff[kSplitSteps];
 #pragma unroll
     for (int q = 0; q < kSplitSteps; ++q) eoff[q] = eofftab[2 * q + lh];
-    const int wlane = lh * W_HALF + li * 16;
+    int wlq[kSplitSteps];  // this lane's row slot inside the (step, half) plane: swizzled like the producers' writes
+#pragma unroll
+    for (int q = 0; q < kSplitSteps; ++q) wlq[q] = lh * W_HALF + (li ^ ((2 * q + lh) & 7)) * 16;
 
     f32x16 acc[TN][TM];
 #pragma unroll
@@ -470,7 +582,7 @@ __global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
     if (cstamp) dbg_[0] = __builtin_amdgcn_s_memtime();
     for (int st = 0; st < NS; ++st) {
       if (cstamp && st < 60) dbg_[2 + 2 * st] = __builtin_amdgcn_s_memtime();
-      const char* const Wt = wbuf + (st & 1) * W_BYTES + wlane;
+      const char* const Wt = wbuf + (st & 1) * W_BYTES;
       const char* const Xt = xbuf + (st & 1) * X_BYTES;
       int nstep = NSTEP;  // the last stage may hold fewer octets
       if ((st + 1) * NO > G8) {
@@ -484,7 +596,7 @@ __global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
 #pragma unroll
           for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) wf[i][p] = *reinterpret_cast<const bf16x8*>(Wt + q * W_STEP + p * W_PIECE + i * 32 * 16);
+            for (int p = 0; p < NP; ++p) wf[i][p] = *reinterpret_cast<const bf16x8*>(Wt + wlq[q] + q * W_STEP + p * W_PIECE + i * 32 * 16);
 #pragma unroll
           for (int j = 0; j < TM; ++j) {
             const char* const px = Xt + colb[j] + eoff[q];
@@ -507,10 +619,13 @@ __global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
         }
       }
       if (cstamp && st < 60) dbg_[2 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
+      if (kl_block) kl_group();
       __syncthreads();
     }
+    if (kl_block) kl_finish();
     if (cstamp) dbg_[1] = __builtin_amdgcn_s_memtime();
-    __syncthreads();  // the producers have staged bias / output-stage constants
+    __syncthreads();  // the producers have staged bias / output-stage constants; every consumer wave has published its KL partial
+    if (kl_block && wave == 0) kl_ticket();
 
     // ---- output stage + store (bt_fused_fast.h: lane = one channel, registers 4q..4q+3 = 4 consecutive positions) ----
     if (a.out_vec4) {
@@ -541,21 +656,29 @@ __global__ __launch_bounds__(512) void fused_split_kernel(const FwdArgs a) {
         readout_quads(i, tid);
       }
     } else {
+      // Scalar stores: lanes run along the channels (consecutive addresses when Ho*Wo == 1: Linear and 1x1 maps).
+      float bsv[TN], scv[TN], shv[TN];
+      bool cok[TN];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int co_l = i * 32 + li;
+        bsv[i] = bias0[co_l], scv[i] = osc[co_l], shv[i] = osh[co_l];
+        cok[i] = n0 + co_l < a.Cog;
+      }
+      const int HoWo = a.Ho * a.Wo;
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          const int co_l = i * 32 + li;
-          const bool cok = n0 + co_l < a.Cog;
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          int bb, hh, ww;
+          const bool live = col_decode(wm * WTM + j * 32 + row, bb, hh, ww);
+          const uint32_t base = (uint32_t)((bb * a.Co + g * a.Cog + n0) * HoWo + hh * a.Wo + ww);  // channel n0 of this pixel
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            int bb, hh, ww;
-            const bool live = col_decode(wm * WTM + j * 32 + row, bb, hh, ww);
-            if (live && cok) {
-              const uint32_t oi = (uint32_t)(((bb * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hh) * a.Wo + ww);
-              float v = __fadd_rn(acc[i][j][r], bias0[co_l]);
-              v = __fadd_rn(__fmul_rn(v, osc[co_l]), osh[co_l]);
+          for (int i = 0; i < TN; ++i) {
+            if (live && cok[i]) {
+              const uint32_t oi = base + (uint32_t)((i * 32 + li) * HoWo);
+              float v = __fadd_rn(__fmul_rn(__fadd_rn(acc[i][j][r], bsv[i]), scv[i]), shv[i]);
               if (res_s) v = __fadd_rn(v, res_s[oi]);
               v = (relu && v < 0.f) ? 0.f : v;
               out_s[oi] = v;

@@ -19,12 +19,54 @@ static int contraction_mode() {
   return m;
 }
 
-// Tile geometry as bt_fused_dispatch.h's fast_geometry, with the split flavour's capacity: the patch of ONE octet plane
-// (worst case: every tap active) has to fit XPO pixels. Returns the number of live columns of a tile (0: does not fit).
+// Extent of the window of taps that can meet data along one axis (the kernel's own rule: bt_fused_split.h), for the whole
+// output axis or -- pixel-major tiles prune per pixel -- the widest window of any single output position.
+static void tap_window(int K, int D, int S, int P, int In, int Out, bool per_pixel, int* n_act, int* extent) {
+  int best_n = 0, best_ext = 0;
+  if (per_pixel) {
+    for (int o = 0; o < Out; ++o) {
+      int lo = 1 << 30, hi = -1, n = 0;
+      for (int k = 0; k < K; ++k)
+        if ((unsigned)(o * S - P + k * D) < (unsigned)In) lo = k * D < lo ? k * D : lo, hi = k * D > hi ? k * D : hi, ++n;
+      if (n > best_n) best_n = n;
+      if (hi - lo > best_ext) best_ext = hi - lo;
+    }
+  } else {
+    int lo = 1 << 30, hi = -1;
+    for (int k = 0; k < K; ++k) {
+      const int l = P - k * D, c = l > 0 ? (l + S - 1) / S : 0;
+      if (c < Out && c * S - l < In) lo = k * D < lo ? k * D : lo, hi = k * D > hi ? k * D : hi, ++best_n;
+    }
+    best_ext = hi >= lo ? hi - lo : 0;
+  }
+  *n_act = best_n, *extent = best_ext;
+}
+
+// Stride-1 tiles of whole output rows: does the patch (window of the active taps) cover every column of the input rows? Then
+// the halo of the patch is zero padding only and the x fetch can move whole 16-byte row pieces (XM 3).
+static bool split_rows_cover(const FwdArgs& a) {
+  int lo = 1 << 30, hi = -1;
+  for (int k = 0; k < a.KW; ++k) {
+    const int l = a.PW - k * a.DW, c = l > 0 ? l : 0;  // stride 1
+    if (c < a.Wo && c - l < a.W) lo = k * a.DW < lo ? k * a.DW : lo, hi = k * a.DW > hi ? k * a.DW : hi;
+  }
+  if (hi < 0) return false;
+  const int x_lo = -a.PW + lo, x_hi = (a.Wo - 1) - a.PW + hi;  // first / last input column of the patch
+  return x_lo <= 0 && x_hi >= a.W - 1;
+}
+
+// Tile geometry as bt_fused_dispatch.h's fast_geometry, with the split flavour's capacity: the patch of ONE octet plane has to
+// fit XPO pixels. Fills the tile fields and returns the tile's live columns (0: does not fit).
 template <int BM>
 static int split_geometry(FwdArgs& a) {
-  constexpr long long XPO = split_xpo<BM>();
-  const int dys = (a.KH - 1) * a.DH, dxs = (a.KW - 1) * a.DW;
+  int nh, nw, dys, dxs;
+  tap_window(a.KH, a.DH, a.SH, a.PH, a.H, a.Ho, a.pixel_major != 0, &nh, &dys);
+  tap_window(a.KW, a.DW, a.SW, a.PW, a.W, a.Wo, a.pixel_major != 0, &nw, &dxs);
+  // One active tap: the canonical K order pairs consecutive octets in one MFMA step, so a stage has to hold TWO octet planes
+  // whatever the tile (otherwise the pairing, and with it the rounding, would depend on the tile choice). Pixel-major tiles can
+  // meet one-tap pixels next to many-tap ones: same rule.
+  const bool one_tap = a.pixel_major || nh * nw <= 1;
+  const long long XPO = one_tap ? split_xpo<BM>() / 2 : split_xpo<BM>();
   auto fits = [&](int NI, int R, int Wt) {
     const long long PHt = (long long)(R - 1) * (dys ? a.SH : 1) + dys + 1, PWt = (long long)(Wt - 1) * (dxs ? a.SW : 1) + dxs + 1;
     return NI * PHt * PWt <= XPO;
@@ -47,21 +89,20 @@ static int split_geometry(FwdArgs& a) {
     NI = 1, R = 1, Wt = BM;  // a segment of one row
     if (!fits(NI, R, Wt)) return 0;
   }
-  const bool grid = a.pixel_major || a.HoWo > 1;
   a.t_NI = NI, a.t_R = R, a.t_Wt = Wt;
   a.n_bt = (a.B + NI - 1) / NI;
-  a.n_rt = grid && !a.pixel_major ? (a.Ho + R - 1) / R : (a.pixel_major ? a.Ho : 1);
-  a.n_ct = grid && !a.pixel_major ? (a.Wo + Wt - 1) / Wt : (a.pixel_major ? a.Wo : 1);
+  a.n_rt = a.pixel_major ? a.Ho : (a.HoWo > 1 ? (a.Ho + R - 1) / R : 1);
+  a.n_ct = a.pixel_major ? a.Wo : (a.HoWo > 1 ? (a.Wo + Wt - 1) / Wt : 1);
   a.m_tiles = a.n_bt * a.n_rt * a.n_ct;
   return NI * R * Wt;
 }
 
-template <int BM, int NP>
+template <int BM, int NP, int NPW, int XM>
 static int launch_split_cfg(FwdArgs& a, hipStream_t stream) {
   constexpr int BN = 64;
   constexpr int lds = split_lds_bytes<BN, BM, NP>();
   static_assert(lds <= 160 * 1024, "LDS budget of one CU");
-  auto kern = fused_split_kernel<BN, BM, NP>;
+  auto kern = fused_split_kernel<BN, BM, NP, NPW, XM>;
   static bool flags[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return set_error(BT_ERR_HIP_BASE, "fused forward (split): hipGetDevice failed");
@@ -71,10 +112,22 @@ static int launch_split_cfg(FwdArgs& a, hipStream_t stream) {
     flags[dev] = true;
   }
   char nm[160];
-  snprintf(nm, sizeof(nm), "fused_split_kernel<%d,%d,bf16x%d,%d terms>", BN, BM, NP, NP == 3 ? 6 : 3);
+  snprintf(nm, sizeof(nm), "fused_split_kernel<%d,%d,bf16x%d,%d terms,npw=%d,xm=%d>", BN, BM, NP, NP == 3 ? 6 : 3, NPW, XM);
   note_kernel(nm);
-  hipLaunchKernelGGL(kern, dim3((unsigned)a.total_blocks), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.total_blocks), dim3(256 + 64 * NPW), lds, stream, a);
   return check_launch("fused forward (split)");
+}
+
+template <int BM, int NPW>
+static int launch_split_xm(FwdArgs& a, int mode, int xm, hipStream_t stream) {
+  if (mode == 2) return launch_split_cfg<BM, 2, NPW, 0>(a, stream);   // (the opt-in 3-term form keeps the generic fetch)
+  if constexpr (BM == 128) {
+    if (xm == 1) return launch_split_cfg<BM, 3, NPW, 1>(a, stream);
+    if (xm == 2) return launch_split_cfg<BM, 3, NPW, 2>(a, stream);
+  } else {
+    if (xm == 3) return launch_split_cfg<BM, 3, NPW, 3>(a, stream);
+  }
+  return launch_split_cfg<BM, 3, NPW, 0>(a, stream);
 }
 
 // Returns BT_OK when the launch was taken, 1 when this flavour does not apply (the caller runs the fp32 kernels), < 0 on error.
@@ -86,23 +139,43 @@ int launch_split(FwdArgs& a, hipStream_t stream) {
       a.x_elems >= (1ll << 29))
     return 1;
   const int Mdom = a.pixel_major ? a.B : a.M;
-  if (Mdom < 256) return 1;
+  if (Mdom < 112) return 1;
   a.n_tiles = (a.Cog + 63) / 64;
-  FwdArgs b512 = a, b256 = a;
+  FwdArgs b512 = a, b256 = a, b128 = a;
   const int live512 = Mdom >= 512 ? split_geometry<512>(b512) : 0;
-  const int live256 = split_geometry<256>(b256);
-  const long long t512 = live512 ? (long long)a.G * a.n_tiles * a.S * b512.m_tiles : 0;
+  const int live256 = Mdom >= 256 ? split_geometry<256>(b256) : 0;
+  const int live128 = split_geometry<128>(b128);
+  const long long per = (long long)a.G * a.n_tiles * a.S;
+  // Cost of a launch in column-equivalents: rounds of 256 workgroups x (the tile's columns, but never less than the weight
+  // synthesis of a stage costs the producers, + the prologue / output stage of a workgroup). Tiles that waste more than a
+  // quarter of their columns are not considered.
+  auto cost = [&](int live, int BM, const FwdArgs& b) -> double {
+    if (!live) return 1e30;
+    const double eff = (double)a.M / ((double)b.m_tiles * BM);
+    if (eff < 0.75) return 1e30;
+    const double rounds = (double)((per * b.m_tiles + 255) / 256);
+    return rounds * ((BM > 256 ? BM : 256) + 96);
+  };
+  const double c512 = cost(live512, 512, b512), c256 = cost(live256, 256, b256), c128 = cost(live128, 128, b128);
   int bm = 0;
-  if (live512 * 100 >= 512 * 85 && t512 >= 256) bm = 512;       // the wide tile when it is filled and the grid covers the chip
-  else if (live256 * 100 >= 256 * 85) bm = 256;
+  if (c512 < 1e30 && c512 <= c256 && c512 <= c128) bm = 512;
+  else if (c256 < 1e30 && c256 <= c128) bm = 256;
+  else if (c128 < 1e30) bm = 128;
   if (!bm) return 1;
-  a = bm == 512 ? b512 : b256;
-  const long long total = (long long)a.G * a.n_tiles * a.S * a.m_tiles;
+  a = bm == 512 ? b512 : bm == 256 ? b256 : b128;
+  const long long total = per * a.m_tiles;
   if (total <= 0 || total > 0x7FFFFFFFll) return 1;
   a.total_blocks = (int)total;
   a.kl_slices = total < 256 ? (int)total : 256;
-  if (bm == 512) return mode == 2 ? launch_split_cfg<512, 2>(a, stream) : launch_split_cfg<512, 3>(a, stream);
-  return mode == 2 ? launch_split_cfg<256, 2>(a, stream) : launch_split_cfg<256, 3>(a, stream);
+  // x fetch mode (bt_fused_split.h): tiny input planes are read as 16-byte vectors
+  const bool xal = (((uintptr_t)a.x) & 15u) == 0 && (a.x_sample_stride & 3) == 0;
+  int xm = 0;
+  if (xal && a.HW == 1) xm = 1;
+  else if (xal && bm != 128 && !a.pixel_major && a.HW > 1 && a.SH == 1 && a.SW == 1 && (a.W & 3) == 0 && a.t_Wt == a.Wo && split_rows_cover(a)) xm = 3;
+  else if (xal && a.pixel_major && a.H == 2 && a.W == 2 && a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.SH == 1 && a.SW == 1 && a.DH == 1 && a.DW == 1) xm = 2;
+  if (bm == 512) return launch_split_xm<512, 4>(a, mode, xm, stream);
+  if (bm == 256) return launch_split_xm<256, 4>(a, mode, xm, stream);
+  return launch_split_xm<128, 8>(a, mode, xm, stream);
 }
 
 }  // namespace bt

@@ -23,6 +23,11 @@ GEOMS = {
     "dilation 2": (16, 32, (3, 3), 1, 2, 2, 1, 16, 16, 8, 1, True),
     "groups 2, 3x2 kernel, stride (2,1)": (32, 48, (3, 2), (2, 1), (1, 0), 1, 2, 16, 9, 8, 1, True),
     "K = 4608 (512x512 3x3 on 4x4)": (512, 64, (3, 3), 1, 1, 1, 1, 4, 4, 32, 1, False),
+    "layer4 512x512 3x3 on 1x1 maps (128 tile, 1 of 9 taps, xm=1)": (512, 512, (3, 3), 1, 1, 1, 1, 1, 1, 128, 2, False),
+    "layer3 256x256 3x3 on 2x2 maps (pixel-major, 4 of 9 taps, xm=2)": (256, 256, (3, 3), 1, 1, 1, 1, 2, 2, 128, 2, False),
+    "layer3.0.conv1 128->256 3x3 s2 4x4->2x2 (pixel-major, generic fetch)": (128, 256, (3, 3), 2, 1, 1, 1, 4, 4, 128, 2, True),
+    "layer4.0.downsample 256->512 1x1 s2 2x2->1x1": (256, 512, (1, 1), 2, 0, 1, 1, 2, 2, 128, 2, False),
+    "1x1 maps, partial batch tile (B = 120)": (64, 96, (3, 3), 1, 1, 1, 1, 1, 1, 120, 1, True),
 }
 
 
@@ -86,7 +91,7 @@ def test_split_kernel_vs_c_oracle_and_fp32_kernel(name):
 
 
 def test_split_kernel_is_independent_of_tiling_and_launch_split():
-    """Canonical K order: the same global samples in one launch (512-wide tiles) or in eight launches of two (256-wide
+    """Canonical K order: the same global samples in one launch (512-wide tiles) or in eight launches of two (narrower
     tiles: fewer workgroups), a whole batch or its first rows (another tile geometry), shared or stacked x -- bit for bit
     the same numbers."""
     mu, rho, mb, rb, x, conv, B, S = _case("layer1 64x64 3x3 8x8 (512 tile, 9 taps)")
@@ -96,7 +101,7 @@ def test_split_kernel_is_independent_of_tiling_and_launch_split():
     parts = []
     for s0 in range(0, 16, 2):
         o, kn2 = _run(mu, rho, None, None, x1, conv, 2, 0, sample0=5 + s0, shared=True)
-        assert "<64,256" in kn2, kn2
+        assert "fused_split_kernel" in kn2 and "<64,512" not in kn2, kn2     # fewer workgroups: a narrower tile
         parts.append(o)
     assert torch.equal(torch.cat(parts), full)
     stacked, _ = _run(mu, rho, None, None, torch.cat([x1, x1]), conv, 2, 0)
@@ -156,3 +161,40 @@ def test_model_level_parity_with_split_kernels():
         _lib.lib().bt_set_contraction(0)
     assert_close(logits.cpu(), l32.cpu(), RTOL, ATOL, "split vs fp32 kernels, same draws")
     assert float(kl) == float(kl32)
+
+
+@pytest.mark.parametrize("In,Out,B,S,bias", [(512, 10, 128, 2, True), (3072, 512, 256, 1, True), (520, 40, 128, 1, False)])
+def test_linear_layers_on_the_split_kernel(In, Out, B, S, bias):
+    """LinearReparameterization == a 1x1 convolution over 1x1 images (cfg2's MLP, the ResNet heads)."""
+    from oracle import c_oracle as CO
+    from bayesian_torch_amd import _lib
+    from bayesian_torch_amd import functional as F
+    g = torch.Generator().manual_seed(In + Out)
+    mu, rho = torch.randn(Out, In, generator=g) * 0.1, torch.randn(Out, In, generator=g) * 0.1 - 3
+    mb = torch.randn(Out, generator=g) * 0.1 if bias else None
+    rb = torch.randn(Out, generator=g) * 0.1 - 3 if bias else None
+    x = torch.randn(B, In, generator=g)
+    c = lambda t: None if t is None else t.cuda()
+    out, _ = F.fused_forward(c(x), c(mu), c(rho), c(mb), c(rb), S=S, seed=3, call=1, layer_id=4, sample0=2, packed=F.pack_params(c(mu), c(rho)))
+    kn = _lib.lib().bt_last_kernel_name().decode()
+    assert "fused_split_kernel" in kn, kn
+    dev = torch.device("cuda")
+    eps_w = F.rng_fill_normal(3, 1, 4, 2, 0, S, mu.shape, dev).cpu()
+    eps_b = F.rng_fill_normal(3, 1, 4, 2, 1, S, (Out,), dev).cpu() if bias else None
+    out = out.reshape(S, B, Out).cpu()
+    for s in range(S):
+        ref = CO.reparam_fwd(x, mu, rho, eps_w[s], mb, rb, None if eps_b is None else eps_b[s], None)
+        assert_close(out[s], ref, RTOL, ATOL, f"linear {In}->{Out} sample {s}")
+
+
+def test_fp32_kernel_repeatability_on_a_padded_channel_chunk():
+    """24 input channels (a channel chunk padded to 32) on the fp32 kernels: 30 identical launches give 30 identical, finite
+    results (guards the padded rows of the fp32 flavour's K-stages against stale LDS)."""
+    mu, rho, mb, rb, x, conv, B, S = _case("odd octet count, one tap")
+    first = None
+    for _ in range(30):
+        out, kn = _run(mu, rho, mb, rb, x, conv, S, 1)
+        assert "split" not in kn
+        assert torch.isfinite(out).all(), "non-finite output from " + kn
+        first = out if first is None else first
+        assert torch.equal(out, first)

@@ -10,6 +10,7 @@ import argparse
 ap = argparse.ArgumentParser(); ap.add_argument("--shape", default="layer1"); ap.add_argument("--S", type=int, default=32); ap.add_argument("--B", type=int, default=128); ap.add_argument("--sigma", action="store_true"); ap.add_argument("--noprio", action="store_true"); ap.add_argument("--pool", action="store_true")
 a = ap.parse_args()
 SH = {"conv1": (3, 64, 7, 2, 3, 32), "layer1": (64, 64, 3, 1, 1, 8), "layer2": (128, 128, 3, 1, 1, 4), "layer3": (256, 256, 3, 1, 1, 2), "layer4": (512, 512, 3, 1, 1, 1)}
+pri = None
 Ci, Co, k, st, pd, H = SH[a.shape]
 dev = torch.device("cuda")
 mu = torch.randn(Co, Ci, k, k, device=dev) * 0.1; rho = torch.randn(Co, Ci, k, k, device=dev) * 0.1 - 3
@@ -21,7 +22,9 @@ L = _lib.lib(); L.bt_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]; L.bt_d
 for i in range(3):
     F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=i, layer_id=3)
 L.bt_debug_set_stamp_buffer(buf.data_ptr())
-F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=9, layer_id=3, packed=(F.pack_params(mu, rho) if a.sigma else None), pool=a.pool, relu=a.pool)
+pri = (torch.zeros_like(mu), torch.ones_like(mu), None, None)
+F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=9, layer_id=3, packed=(F.pack_params(mu, rho) if a.sigma else None), pool=a.pool, relu=a.pool, priors=pri, want_kl=True)
+print(L.bt_last_kernel_name().decode())
 torch.cuda.synchronize()
 L.bt_debug_set_stamp_buffer(None)
 t = buf.cpu().tolist()
