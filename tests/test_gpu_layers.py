@@ -210,7 +210,7 @@ for (In, Out, B, S, flip) in [(512, 10, 128, 2, False), (3072, 512, 64, 1, True)
 torch.save(torch.cat(outs), sys.argv[1])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    for tag, env in (("fast", {}), ("general", {"BT_FORCE_GENERIC": "1"})):
+    for tag, env in (("fast", {"BT_CONTRACTION": "f32"}), ("general", {"BT_CONTRACTION": "f32", "BT_FORCE_GENERIC": "1"})):   # the two fp32-MFMA flavours
         f = str(tmp_path / (tag + ".pt"))
         subprocess.run([sys.executable, "-c", script, f], check=True, env=dict(os.environ, **env), timeout=300)
         res.append(torch.load(f))
@@ -333,7 +333,11 @@ def test_fused_maxpool_output_stage(Ci, Co, k, st, pd, H, W, B, flip, fusable):
     direct = F._fused_forward(cu(x), cu(mu), cu(rho), cu(mb), cu(rb), pool=True, **kw)
     assert (direct is not None) == fusable, "fusability of this geometry changed"
     out, _ = F.fused_forward(cu(x), cu(mu), cu(rho), cu(mb), cu(rb), pool=True, **kw)
-    full, _ = F.fused_forward(cu(x), cu(mu), cu(rho), cu(mb), cu(rb), **kw)
+    _lib.lib().bt_set_contraction(1)       # the pooled output stage lives in the fp32-MFMA kernels: compare like with like
+    try:
+        full, _ = F.fused_forward(cu(x), cu(mu), cu(rho), cu(mb), cu(rb), **kw)
+    finally:
+        _lib.lib().bt_set_contraction(0)
     Ho, Wo = full.shape[2], full.shape[3]
     assert tuple(out.shape) == (S * B, Co, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1)
     # the fused pool is exactly max_pool2d of the unpooled launch's output (same draws, same arithmetic)
