@@ -28,9 +28,9 @@ class FusedBayesLayer(BaseVariationalLayer_):
     _wname = "weight"    # parameter suffix: mu_weight / mu_kernel
 
     # ------------------------------------------------------------------ construction
-    def _build(self, wshape, bias, eps_bias_last=False):
+    def _build(self, wshape, bias, eps_bias_last=False, n_out=None):
         wn = self._wname
-        n_out = wshape[0]
+        n_out = wshape[0] if n_out is None else n_out     # (transposed convolutions: the kernel is [Ci][Co/g]..., the bias [Co])
         self.register_parameter("mu_" + wn, Parameter(torch.empty(wshape)))
         self.register_parameter("rho_" + wn, Parameter(torch.empty(wshape)))
         self.register_buffer("eps_" + wn, torch.zeros(wshape), persistent=False)

@@ -1,9 +1,10 @@
 """``Conv2dFlipout`` -- drop-in for reference ``layers/flipout_layers/conv_flipout.py:247-439`` on the
 two-accumulator fused implicit-GEMM HIP kernel (bt_flipout_conv2d_fwd)."""
+from .._family import Conv3dFlipout, ConvTranspose1dFlipout, ConvTranspose2dFlipout, ConvTranspose3dFlipout  # noqa: F401
 from .._fused import FusedBayesLayer
 from ..base_variational_layer import get_kernel_size
 
-__all__ = ["Conv2dFlipout", "Conv1dFlipout"]
+__all__ = ["Conv2dFlipout", "Conv1dFlipout", "Conv3dFlipout", "ConvTranspose1dFlipout", "ConvTranspose2dFlipout", "ConvTranspose3dFlipout"]
 
 
 class Conv2dFlipout(FusedBayesLayer):

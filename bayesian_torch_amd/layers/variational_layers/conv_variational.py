@@ -1,10 +1,14 @@
 """``Conv2dReparameterization`` -- drop-in for reference
 ``layers/variational_layers/conv_variational.py:234-407`` on the fused implicit-GEMM HIP kernel
-(bt_reparam_conv2d_fwd).  Conv1d/3d/Transpose/Multivariate variants are outside this build's scope."""
+(bt_reparam_conv2d_fwd); Conv1d on the same kernel; Conv3d and ConvTranspose{1,2,3}d come from layers/_family.py (exact index
+re-arrangements around the same launch).  The Multivariate variant is outside this build's scope."""
+from .._family import (Conv3dReparameterization, ConvTranspose1dReparameterization,  # noqa: F401
+                       ConvTranspose2dReparameterization, ConvTranspose3dReparameterization)
 from .._fused import FusedBayesLayer
 from ..base_variational_layer import get_kernel_size
 
-__all__ = ["Conv2dReparameterization", "Conv1dReparameterization"]
+__all__ = ["Conv2dReparameterization", "Conv1dReparameterization", "Conv3dReparameterization", "ConvTranspose1dReparameterization",
+           "ConvTranspose2dReparameterization", "ConvTranspose3dReparameterization"]
 
 
 class Conv2dReparameterization(FusedBayesLayer):

@@ -2,7 +2,7 @@
 
 Same contract: in-place recursive swap of leaf modules whose class name contains "Conv" /
 "Linear" by ``<ClassName><params['type']>`` looked up in ``bayesian_torch_amd.layers``
-(AttributeError when that class does not exist: Conv3d / ConvTranspose are outside this build), same dict keys (KeyError when one is missing), MOPED initialisation, and
+(AttributeError when that class does not exist), same dict keys (KeyError when one is missing), MOPED initialisation, and
 ``dnn_to_bnn_flag = True`` on every created layer.  ``get_kl_loss`` gathers every fused layer's
 (mu, rho, prior) tensors into ONE bt_kl_normal launch instead of ~12 ATen passes per layer.
 """

@@ -84,8 +84,12 @@ def test_negative_paths_match_reference():
         dnn_to_bnn(nn.Sequential(nn.Linear(2, 2)), bad)
     with pytest.raises(AttributeError, match="LinearFoo"):
         dnn_to_bnn(nn.Sequential(nn.Linear(2, 2)), dict(PRIOR, type="Foo"))
-    with pytest.raises(AttributeError):       # Conv3d / ConvTranspose layers are outside this build
-        dnn_to_bnn(nn.Sequential(nn.Conv3d(2, 2, 3)), PRIOR)
+    with pytest.raises(AttributeError):       # class looked up by name: a layer kind the package does not have
+        dnn_to_bnn(nn.Sequential(nn.LazyConv2d(2, 3)), PRIOR)
+    m3 = nn.Sequential(nn.Conv3d(2, 2, 3), nn.ConvTranspose2d(2, 4, 3, stride=2))     # the rest of the conv family converts, as in the reference
+    dnn_to_bnn(m3, PRIOR)
+    assert type(m3[0]).__name__ == "Conv3dReparameterization" and type(m3[1]).__name__ == "ConvTranspose2dReparameterization"
+    assert tuple(m3[1].mu_kernel.shape) == (2, 4, 3, 3) and m3[1].dnn_to_bnn_flag
     seq = nn.Sequential(nn.LSTM(3, 5), nn.Conv1d(2, 4, 3))
     dnn_to_bnn(seq, PRIOR)
     assert repr(seq[0]) == "LSTMReparameterization(\n  (ih): LinearReparameterization()\n  (hh): LinearReparameterization()\n)"
