@@ -53,6 +53,10 @@ _PROTOS = {
     "bt_last_error_string": (C.c_char_p, []),
     "bt_last_kernel_name": (C.c_char_p, []),
     "bt_set_contraction": (C.c_int, [C.c_int]),
+    "bt_conv2d_bwd_workspace": (C.c_size_t, [C.POINTER(bt_conv2d_geom), C.c_int32]),
+    "bt_conv2d_bwd": (C.c_int, [C.POINTER(bt_conv2d_geom), C.c_int32, C.c_int32, _vp, C.c_int64, _vp, C.POINTER(bt_params), C.POINTER(bt_draws),
+                                _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "bt_kl_normal_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_uint32, _vp, _vp, _vp]),
     "bt_reparam_linear_fwd": (C.c_int, [C.c_int32] * 4 + _FWD_TAIL),
     "bt_flipout_linear_fwd": (C.c_int, [C.c_int32] * 4 + _FWD_TAIL),
     "bt_reparam_conv2d_fwd": (C.c_int, [C.POINTER(bt_conv2d_geom), C.c_int32] + _FWD_TAIL),

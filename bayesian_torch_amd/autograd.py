@@ -1,15 +1,18 @@
-"""Autograd bridge for the fused forward (SURVEY.md section 8(f), rank 1 -- first step).
+"""Autograd bridge for the fused forward.
 
-The forward stays the fused HIP kernel.  Nothing weight-sized is saved for backward: the draws are a pure function of
-the RNG coordinates, so backward REGENERATES eps (and the Flipout signs) with bt_rng_*_fill from the coordinates the
-forward used, rebuilds W_s = mu + softplus(rho) * eps_s, and obtains the three gradients of the contraction
-(d/dx, d/dW, d/db) from ATen's convolution / matmul backward on the GPU; the chain rule to (mu, rho) is applied here:
+The forward is the fused HIP kernel; the backward is the pair of hand-written HIP kernels of csrc/bt_bwd.hip
+(bt_conv2d_bwd: data gradient and weight gradient as implicit GEMMs on fp32 MFMA).  Nothing weight-sized is saved for
+backward and nothing weight-sized is materialised in it: the draws are a pure function of the RNG coordinates, so the
+kernels REGENERATE eps (and the Flipout signs) from the coordinates the forward used, inside their operand staging, and
+the weight-gradient kernel applies the chain rule to (mu, rho) in its output stage:
 
-    dL/dmu  = sum_s dL/dW_s                       dL/drho  = sum_s dL/dW_s * eps_s * sigmoid(rho)
+    dL/dmu  = sum_s dL/dW_s                       dL/drho  = sigmoid(rho) * sum_s dL/dW_s * eps_s
     (Flipout: mean path feeds mu, perturbation path feeds rho through Delta = softplus(rho) * eps)
 
-This is an interim backward: correct (tests/test_gpu_autograd.py checks it against torch autograd of the oracle on the
-same draws) but not yet fused -- a hand-written HIP dgrad/wgrad with in-kernel regeneration is the next step.
+The KL term's gradient is the element-wise HIP kernel bt_kl_normal_bwd.  Bias gradients are row sums of the upstream
+gradient (a [S, Co] reduction) times the regenerated bias draw -- bias-sized, done with torch.sum.
+``BACKWARD_IMPL = "aten"`` selects round 1's checker path (draws materialised with bt_rng_*_fill, ATen convolution
+backward per sample): tests compare the two; the product default is "hip".
 Reference arithmetic differentiated: layers/variational_layers/linear_variational.py:163-181,
 conv_variational.py:366-385, flipout_layers/linear_flipout.py:149-174, conv_flipout.py:376-417 and the normal-prior
 KL of base_variational_layer.py:68-72.
@@ -36,6 +39,9 @@ def _grads(x, w, g, conv, need_x=True):
     return gx, gw
 
 
+BACKWARD_IMPL = "hip"     # "aten": the materialising checker path below (tests only)
+
+
 class FusedForward(torch.autograd.Function):
     """out[S*B, ...] = fused stochastic forward; differentiable in x, mu_w, rho_w, mu_b, rho_b."""
 
@@ -60,6 +66,30 @@ class FusedForward(torch.autograd.Function):
         g = g.contiguous()
         B = x.shape[0] // (1 if shared else S)
         coords = (o["seed"], o["call"], o["layer_id"], o["sample0"])
+        if BACKWARD_IMPL == "hip":
+            need_x = ctx.needs_input_grad[0]
+            need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+            packed = o.get("packed") or F.pack_params(mu_w.detach(), rho_w.detach())
+            gx, gmu, grho = F.fused_backward(x, g, mu_w.detach(), rho_w, packed, flip=flip, conv=conv, S=S, shared_x=shared, need_x=need_x, need_w=need_w,
+                                             eps_w=o.get("eps_w"), sign_in=o.get("sign_in"), sign_out=o.get("sign_out"),
+                                             seed=o["seed"], call=o["call"], layer_id=o["layer_id"], sample0=o["sample0"])
+            gmu_b = grho_b = None
+            if mu_b is not None:
+                Co = mu_w.shape[0]
+                gs = g.reshape((S, B, Co, -1))
+                if flip:       # out = mean + (pert + Delta_b) o s_out: mu_b sees g, the bias perturbation sees g o s_out
+                    s_out = o.get("sign_out")
+                    if s_out is None:
+                        s_out = F.rng_fill_sign(*coords, 3, S, (B,) + tuple(ctx.out_shape[1:]), dev)
+                    gp = (g.reshape(s_out.shape) * s_out).reshape((S, B, Co, -1)).sum((1, 3))
+                else:
+                    gp = gs.sum((1, 3))
+                eps_b = o.get("eps_b")
+                if eps_b is None:
+                    eps_b = F.rng_fill_normal(*coords, 1, S, (Co,), dev)
+                gmu_b = gs.sum((0, 1, 3))
+                grho_b = (gp * eps_b.reshape(S, Co)).sum(0) * torch.sigmoid(rho_b)
+            return gx, gmu, grho, gmu_b, grho_b, None
         # the draws of the forward, regenerated (or the injected ones)
         eps_w = o.get("eps_w")
         if eps_w is None:
@@ -133,6 +163,11 @@ class KLNormal(torch.autograd.Function):
     def backward(ctx, g):
         t = ctx.saved_tensors
         grads = [None]
+        if BACKWARD_IMPL == "hip":
+            for i in range(0, len(t), 4):
+                gmu, grho = F.kl_backward(t[i], t[i + 1], t[i + 2], t[i + 3], g, laplace=ctx.kind == "laplace")
+                grads += [gmu, grho, None, None]
+            return tuple(grads)
         for i in range(0, len(t), 4):
             mu, rho, pm, ps = t[i:i + 4]
             n = mu.numel()

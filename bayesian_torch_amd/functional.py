@@ -167,3 +167,51 @@ def mc_epilogue(logits):
     with _lib.on(logits.device):
         _lib.check(_lib.lib().bt_mc_epilogue(S, B, Cc, logits.data_ptr(), packed.data_ptr(), _lib.stream_ptr(logits.device)))
     return packed
+
+
+def fused_backward(x, grad_out, mu_w, rho_w, packed, *, flip=False, conv=None, S=1, shared_x=True, need_x=True, need_w=True,
+                   eps_w=None, sign_in=None, sign_out=None, seed=0, call=0, layer_id=0, sample0=0):
+    """Gradients of ``fused_forward`` on the HIP backward kernels (bt_conv2d_bwd): the draws are regenerated on chip from the
+    forward's RNG coordinates (or the injected ones are read).  x / grad_out as the forward saw / produced them.
+    -> (dx like x or None, dmu_w, drho_w like mu_w or None).  Bias gradients are row sums of grad_out (caller)."""
+    x, g = _lib.dev_f32(x, "input"), _lib.dev_f32(grad_out, "grad_out")
+    dev = x.device
+    mu_w, rho_w = _lib.dev_f32(mu_w, "mu_w"), _lib.dev_f32(rho_w.detach(), "rho_w")
+    B = x.shape[0] // (1 if shared_x else S)
+    Co = mu_w.shape[0]
+    if conv is None:
+        geom = _lib.bt_conv2d_geom(B, mu_w.shape[1], 1, 1, Co, 1, 1, 1, 1, 0, 0, 1, 1, 1)
+    else:
+        (sh, sw), (ph, pw), (dh, dw), groups = conv["stride"], conv["padding"], conv["dilation"], conv["groups"]
+        geom = _lib.bt_conv2d_geom(B, x.shape[1], x.shape[2], x.shape[3], Co, mu_w.shape[2], mu_w.shape[3], sh, sw, ph, pw, dh, dw, groups)
+    x_elems = x.numel() // (1 if shared_x else S)
+    dx = torch.empty((S,) + (B,) + tuple(x.shape[1:]), dtype=torch.float32, device=dev) if need_x else None
+    dmu = torch.empty_like(mu_w) if need_w else None
+    drho = torch.empty_like(mu_w) if need_w else None
+    L = _lib.lib()
+    ws = None
+    if need_w:
+        ws = torch.empty(max(16, L.bt_conv2d_bwd_workspace(C.byref(geom), S)), dtype=torch.uint8, device=dev)
+    inj = [None if t is None else _lib.dev_f32(t, "draw") for t in (eps_w, sign_in, sign_out)]
+    P = _lib.bt_params(mu_w.data_ptr(), rho_w.data_ptr(), None, None, None, None, None, None, packed[0].data_ptr(), packed[1].data_ptr(), 0, 0)
+    R = _rng(seed, call, layer_id, sample0, None)
+    D = _lib.bt_draws(_lib.ptr(inj[0]), None, _lib.ptr(inj[1]), _lib.ptr(inj[2]), R)
+    with _lib.on(dev):
+        _lib.check(L.bt_conv2d_bwd(C.byref(geom), S, 1 if flip else 0, x.data_ptr(), 0 if shared_x else x_elems, g.data_ptr(), C.byref(P), C.byref(D),
+                                   _lib.ptr(dx), _lib.ptr(dmu), _lib.ptr(drho), _lib.ptr(ws), 0 if ws is None else ws.numel(), _lib.stream_ptr(dev)))
+    if need_x:
+        dx = dx.sum(0) if shared_x else dx.reshape(x.shape)
+    return dx, dmu, drho
+
+
+def kl_backward(mu, rho, prior_mu, prior_sigma, grad_kl, laplace=False):
+    """(d kl / d mu, d kl / d rho) * grad_kl for one tensor of bt_kl_normal's mean (HIP kernel bt_kl_normal_bwd)."""
+    mu, rho = _lib.dev_f32(mu.detach(), "mu"), _lib.dev_f32(rho.detach(), "rho")
+    pm = None if laplace else _lib.dev_f32(prior_mu, "prior_mu")
+    ps = None if laplace else _lib.dev_f32(prior_sigma, "prior_sigma")
+    g = _lib.dev_f32(grad_kl.reshape(1).contiguous(), "grad_kl")
+    dmu, drho = torch.empty_like(mu), torch.empty_like(mu)
+    with _lib.on(mu.device):
+        _lib.check(_lib.lib().bt_kl_normal_bwd(mu.data_ptr(), rho.data_ptr(), _lib.ptr(pm), _lib.ptr(ps), g.data_ptr(), mu.numel(),
+                                               _lib.KL_PRIOR_LAPLACE if laplace else 0, dmu.data_ptr(), drho.data_ptr(), _lib.stream_ptr(mu.device)))
+    return dmu, drho

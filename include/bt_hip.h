@@ -193,6 +193,25 @@ int bt_rng_normal_fill(const bt_rng *rng, uint32_t tensor_id, int32_t S, int64_t
 int bt_rng_sign_fill(const bt_rng *rng, uint32_t tensor_id, int32_t S, int64_t n, float *out, bt_stream_t stream);
 int bt_rng_philox_raw(uint64_t seed, const uint32_t ctr[4], uint32_t out_host[4]); /* host-side Philox4x32-10 KAT hook */
 
+/* Backward of the four fused forwards (the reference relies on torch autograd of
+ * linear_variational.py:163-181, conv_variational.py:366-385, linear_flipout.py:149-174, conv_flipout.py:376-417).
+ * grad_out is dL/dout [S][B][Co][Ho][Wo] of a forward made with the same (geometry, S, p, d): the draws are REGENERATED on chip
+ * from d->rng (or read, when d carries injected draws) -- nothing weight-sized is written to HBM.
+ *   dx      [S][B][Ci][H][W] or NULL: per-sample input gradient (sum over S yourself when the forward shared x);
+ *   dmu_w / drho_w  the parameters' own layout [Co][Ci/groups][kh][kw], both or neither:
+ *           dmu = sum_s dW_s,  drho = sigmoid(rho) * sum_s eps_s o dW_s  (Flipout: mean path -> mu, perturbation path -> rho);
+ *   workspace: bt_conv2d_bwd_workspace(g, S) bytes (partials of the sample groups; contents need not be initialised).
+ * Linear layers: g = {B, In, 1, 1, Out, 1, 1, 1, 1, 0, 0, 1, 1, 1}. p needs rho_w, mu_packed, sigma_packed. Bias gradients are
+ * row sums of grad_out (not part of this call). */
+size_t bt_conv2d_bwd_workspace(const bt_conv2d_geom *g, int32_t S);
+int bt_conv2d_bwd(const bt_conv2d_geom *g, int32_t S, int32_t flipout, const float *x, int64_t x_sample_stride, const float *grad_out,
+                  const bt_params *p, const bt_draws *d, float *dx, float *dmu_w, float *drho_w,
+                  void *workspace, size_t workspace_bytes, bt_stream_t stream);
+/* Gradient of bt_kl_normal's mean over ONE tensor: dmu[i], drho[i] = d kl / d(mu_i, rho_i) * grad_kl[0] (grad_kl: device
+ * scalar); flags: BT_KL_PRIOR_LAPLACE for the 'laplace' branch (priors unused then). */
+int bt_kl_normal_bwd(const float *mu, const float *rho, const float *prior_mu, const float *prior_sigma, const float *grad_kl,
+                     int64_t numel, uint32_t flags, float *dmu, float *drho, bt_stream_t stream);
+
 /* Contraction arithmetic of the fused forwards (process-wide; default from env BT_CONTRACTION = f32 | bf16x3 | bf16x2):
  *   0  automatic: wherever a launch is eligible, every fp32 operand is cut into three bf16 pieces (an EXACT split of the
  *      24-bit significand) and the product runs as the 6 piece products of weight >= 2^-16 on the bf16 matrix pipe with
