@@ -325,7 +325,9 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
         const uint32_t co = (uint32_t)(g * a.Cog + (rv ? co_g : 0));
         e_off[i] = (co * (uint32_t)T + (uint32_t)tap) * (uint32_t)Cig4 + (uint32_t)(4 * cq);
         l_off[i] = ((ai << lcc) + 4 * cq) * WS + r;
-        c_lim[i] = rv ? Cig4 - 4 * cq : (u < nunits ? 0 : -1);  // 0: slot exists but holds zeros; -1: no slot
+        // 0: slot exists but holds zeros (row outside Cog, or a channel quad past Cig4 when the chunk is wider than the channel
+        // count: those K rows must be written too -- a stale LDS word times a zero activation is not a zero if it is a NaN); -1: no slot
+        c_lim[i] = rv ? (Cig4 - 4 * cq > 0 ? Cig4 - 4 * cq : 0) : (u < nunits ? 0 : -1);
       }
     }
     const int wave_u0 = __builtin_amdgcn_readfirstlane(ptid & ~63);

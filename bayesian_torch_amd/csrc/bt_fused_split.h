@@ -70,6 +70,8 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
   constexpr int PB = 16 * NP;  // bytes per (pixel, octet) of the x patch
   constexpr int W_BYTES = split_w_bytes<BN, NP>(), X_BYTES = split_x_bytes<BM, NP>(), XPO = split_xpo<BM>();
   constexpr int W_STEP = 2 * NP * BN * 16, W_HALF = NP * BN * 16, W_PIECE = BN * 16;
+  // output staging: all BN channels in one pass when the operand buffers are large enough, else 32 at a time
+  constexpr int SROWS = ((4 * BN + BN * (BM + 4)) * 4 <= 2 * (W_BYTES + X_BYTES)) ? BN : 32, NPASS = BN / SROWS;
 
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   char* const wbuf = smem_c;                  // [2][W_BYTES]
@@ -206,9 +208,9 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
   const bool relu = a.ep_relu != 0;
   __syncthreads();  // eofftab, cleared W buffers
 
-  // Read-out of one staged pass of the output tile by all 8 waves (see the output stage below).
-  auto readout_quads = [&](int i, int t0) {
-    constexpr int SROW = BM + 4, SROWS = 32, QROW = BM / 4, NQD = SROWS * QROW, NT_ = kThreadsAll;
+  // Read-out of one staged pass of the output tile (SROWS channels) by every wave (see the output stage below).
+  auto readout_quads = [&](int pass, int t0) {
+    constexpr int SROW = BM + 4, QROW = BM / 4, NQD = SROWS * QROW, NT_ = kThreadsAll;
     constexpr int NITc = (NQD + NT_ - 1) / NT_, U = NITc < 8 ? NITc : 8;
     const float* const stage = smem + 4 * BN;
     for (int c0q = t0; c0q < NQD; c0q += NT_ * U) {
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         const int row = c / QROW, m4 = c - row * QROW;
         int bq, hq, wq;
         const bool mok = col_decode(4 * m4, bq, hq, wq);
-        const int co_l = i * 32 + row;
+        const int co_l = pass * SROWS + row;
         okq[u] = cr < NQD && mok && n0 + co_l < a.Cog;
         oidx[u] = okq[u] ? (uint32_t)(((bq * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hq) * a.Wo + wq) : 0u;
         v[u] = *reinterpret_cast<const float4*>(stage + row * SROW + 4 * m4);
@@ -489,10 +491,10 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     if (a.out_vec4) {  // the consumers pass the output tile through LDS: same barriers and a share of the read-out
       __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        if (i > 0) __syncthreads();
+      for (int ps = 0; ps < NPASS; ++ps) {
+        if (ps > 0) __syncthreads();
         __syncthreads();
-        readout_quads(i, tid);
+        readout_quads(ps, tid);
       }
     }
   } else {
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
 
     // ---- output stage + store (bt_fused_fast.h: lane = one channel, registers 4q..4q+3 = 4 consecutive positions) ----
     if (a.out_vec4) {
-      constexpr int SROW = BM + 4, SROWS = 32;
+      constexpr int SROW = BM + 4;
       static_assert((4 * BN + SROWS * SROW) * 4 <= 2 * (W_BYTES + X_BYTES), "output staging fits the operand buffers");
       float* const stage = smem + 4 * BN;
       float bsv[TN], scv[TN], shv[TN];
@@ -639,21 +641,24 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         bsv[i] = bias0[co_l], scv[i] = osc[co_l], shv[i] = osh[co_l];
       }
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        if (i > 0) __syncthreads();  // the previous pass has been read out
-        float* const srow = stage + li * SROW + wm * WTM + 4 * lh;
+      for (int ps = 0; ps < NPASS; ++ps) {
+        if (ps > 0) __syncthreads();  // the previous pass has been read out
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
+        for (int i = ps * (SROWS / 32); i < (ps + 1) * (SROWS / 32); ++i) {
+          float* const srow = stage + ((i - ps * (SROWS / 32)) * 32 + li) * SROW + wm * WTM + 4 * lh;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float v[4];
+          for (int j = 0; j < TM; ++j) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(__fmul_rn(__fadd_rn(acc[i][j][4 * q + e], bsv[i]), scv[i]), shv[i]);
-            *reinterpret_cast<float4*>(srow + j * 32 + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+            for (int q = 0; q < 4; ++q) {
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(__fmul_rn(__fadd_rn(acc[i][j][4 * q + e], bsv[i]), scv[i]), shv[i]);
+              *reinterpret_cast<float4*>(srow + j * 32 + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+            }
           }
         }
         __syncthreads();
-        readout_quads(i, tid);
+        readout_quads(ps, tid);
       }
     } else {
       // Scalar stores: lanes run along the channels (consecutive addresses when Ho*Wo == 1: Linear and 1x1 maps).

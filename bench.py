@@ -209,6 +209,55 @@ def parity_check(w, dev):
                 how=f"1 sample, batch {B}, on-chip draws replayed through oracle/bt_oracle.py per layer and end to end; max|hip-ref|/max|ref|")
 
 
+def train_bench(args, w, dev, world, rank):
+    """Training throughput of the drop-in (reference loop: examples/main_bayesian_cifar_dnn2bnn.py:402-420 with one MC sample per
+    step): forward (fused HIP kernels) + get_kl_loss + cross-entropy + backward (HIP dgrad / wgrad with on-chip regeneration)
+    + SGD step. Each rank trains its own replica on its own synthetic batch (no gradient all-reduce: the path under test is the
+    layer kernels)."""
+    from bayesian_torch_amd.models.dnn_to_bnn import get_kl_loss
+    net = build_model(w, dev).train()
+    torch.manual_seed(rank)
+    x = torch.randn(*w["x"], device=dev)
+    B = x.shape[0]
+    ncls = 1000 if args.workload == "cfg5" else 10
+    y = torch.randint(0, ncls, (B,), device=dev)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9)
+    rng.set_mode("philox")
+    rng.manual_seed(0)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(net(x), y) + get_kl_loss(net) / B
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    assert torch.isfinite(loss)
+    if rank == 0:
+        print(json.dumps(dict(metric="training MC-samples/sec (forward+KL+backward+SGD step, 1 MC sample per step), " + w["desc"],
+                              value=round(world * args.steps / dt, 2), unit="MC-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                              ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                              data="synthetic", config=dict(workload=w["desc"], batch=B, mc_samples_per_step=1, optimizer="SGD momentum 0.9",
+                                                            backward="HIP dgrad/wgrad kernels, draws regenerated on chip", launch="eager"))))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +273,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured HIP graph")
     ap.add_argument("--no-fuse", action="store_true", help="keep BatchNorm/ReLU/add as separate torch modules")
     ap.add_argument("--layers-json", default="", help="write the per-layer roofline table here")
+    ap.add_argument("--train", action="store_true", help="secondary line: one TRAINING step per MC sample (forward + KL + HIP backward + SGD step, S = 1, BatchNorm in train mode)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -244,6 +294,8 @@ def main():
     dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     w = WORKLOADS[args.workload]
+    if args.train:
+        return train_bench(args, w, dev, world, rank)
     if args.scaling == "strong":
         S_total = args.samples or w["S_total"]
         first, S = mc_dist.shard(S_total, rank, world)

@@ -188,11 +188,14 @@ def test_linear_layers_on_the_split_kernel(In, Out, B, S, bias):
 
 
 def test_fp32_kernel_repeatability_on_a_padded_channel_chunk():
-    """24 input channels (a channel chunk padded to 32) on the fp32 kernels: 30 identical launches give 30 identical, finite
-    results (guards the padded rows of the fp32 flavour's K-stages against stale LDS)."""
+    """24 input channels (a channel chunk padded to 32) on the fp32 kernels, interleaved with split-kernel launches on the
+    same CUs: identical, finite results every time. Regression: the fp32 fast kernel left the K rows of channel quads past
+    Cig4 unwritten, and stale LDS (a NaN pattern) times a zero activation is a NaN."""
     mu, rho, mb, rb, x, conv, B, S = _case("odd octet count, one tap")
     first = None
-    for _ in range(30):
+    for it in range(12):
+        if it % 2 == 0:
+            _run(mu, rho, mb, rb, x, conv, S, 0)      # leaves bf16 pieces (NaN patterns, read as fp32) behind in the CUs' LDS
         out, kn = _run(mu, rho, mb, rb, x, conv, S, 1)
         assert "split" not in kn
         assert torch.isfinite(out).all(), "non-finite output from " + kn

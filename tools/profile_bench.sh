@@ -15,18 +15,18 @@ out = {}
 f = glob.glob(f"gpurun_out/prof_{tag}_stats/**/*kernel_stats.csv", recursive=True)
 if f:
     rows = list(csv.DictReader(open(f[0])))
-    fused = [r for r in rows if "fused_f" in r["Name"]]
+    fused = [r for r in rows if "fused_" in r["Name"]]
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     ft = sum(float(r["TotalDurationNs"]) for r in fused); fc = sum(int(r["Calls"]) for r in fused)
     out["kernel_stats"] = dict(fused_calls=fc, fused_total_ms=ft / 1e6, fused_avg_us=ft / fc / 1e3, fused_share_of_gpu_time=ft / tot)
     print("top kernels:")
-    for r in rows[:8]:
-        print(f"  {r['Percentage']:>6}%  {int(r['Calls']):5d} calls  avg {float(r['AverageNs'])/1e3:9.1f} us  {r['Name'][:110]}")
+    for r in rows[:16]:
+        print(f"  {r['Percentage']:>6}%  {int(r['Calls']):5d} calls  avg {float(r['AverageNs'])/1e3:9.1f} us  {r['Name'][:150]}")
 for name in ("fetch", "write"):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for f in glob.glob(f"gpurun_out/prof_{tag}_{name}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = "fused" if "fused_f" in r["Kernel_Name"] else "other"
+            k = "fused" if "fused_" in r["Kernel_Name"] else "other"
             agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     out[name] = {k: dict(sum=v[0], launches=v[1], per_launch=v[0] / max(1, v[1])) for k, v in agg.items()}
 json.dump(out, open(f"gpurun_out/prof_{tag}_summary.json", "w"), indent=1)
