@@ -59,7 +59,8 @@ __device__ __forceinline__ uint32_t pack_hi16(uint32_t hi, uint32_t lo) {  // (h
 // ones in every stage, so their addresses are decoded once) and issues all their loads one stage ahead.
 //   0: item = (patch pixel, octet): one dword per channel; any geometry.
 //   1: 1x1 input planes (and Linear): item = (image, octet), its 8 channels are 32 contiguous bytes.
-//   2: 2x2 input planes wholly inside the patch: item = (image, octet), a channel's plane is 16 contiguous bytes.
+//   2: 2x2 input planes wholly inside the patch: item = (image, channel pair) -- a channel's plane is 16 contiguous bytes and
+//      consecutive lanes take consecutive channels, so a wave's loads cover whole 256-byte pieces of an image.
 //   3: stride-1 tiles of whole rows with W % 4 == 0: item = (4 consecutive input pixels, half an octet): 16-byte row pieces;
 //      the zero halo of the patch is never written (the buffers are cleared once).
 template <int BN, int BM, int NP, int NPW, int XM>
@@ -282,13 +283,13 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     const int wave_u0 = __builtin_amdgcn_readfirstlane(ptid & ~63);
     // x items of this thread (see XM above): global byte offset of the item at octet 0, LDS byte offset inside an x buffer,
     // octet inside the stage.
-    constexpr int PIT = XM == 2 ? (XPO / 4 + kProducers - 1) / kProducers : XM == 3 ? (XPO / 2 + kProducers - 1) / kProducers : (XPO + kProducers - 1) / kProducers;
-    constexpr int XV = XM == 2 ? 32 : XM == 3 ? 16 : 8;
+    constexpr int PIT = XM == 3 ? (XPO / 2 + kProducers - 1) / kProducers : (XPO + kProducers - 1) / kProducers;
+    constexpr int XV = XM == 3 ? 16 : 8;
     int it_off[PIT], it_lds[PIT], it_ol[PIT];
     // real input rows of the patch and 16-byte quads per row (XM 3)
     const int ylo_r = y_lo > 0 ? y_lo : 0, yhi_r = (y_lo + PHt < a.H) ? y_lo + PHt : a.H;
     const int nyr = yhi_r > ylo_r ? yhi_r - ylo_r : 0, W4 = a.W >> 2;
-    const int per_oct = XM == 2 ? t_NI : XM == 3 ? 2 * t_NI * nyr * W4 : PCH;
+    const int per_oct = XM == 2 ? 4 * t_NI : XM == 3 ? 2 * t_NI * nyr * W4 : PCH;   // XM 2: (image, channel pair) items
     const int n_items = NO * per_oct;
     {
       const uint32_t inv_per = per_oct > 1 ? (uint32_t)((0x100000000ull + (unsigned)per_oct - 1) / (unsigned)per_oct) : 0u;
@@ -308,11 +309,19 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
           r = NO <= 1 ? ff : (int)__umulhi((uint32_t)ff, inv_no);
           ol = ff - r * NO;
         }
+        int pair = 0;
+        if constexpr (XM == 2) {  // channel pair fastest, then octet, then image: r = image
+          const int cps = 4 * NO;   // channel pairs of a stage
+          const uint32_t inv_cps = (uint32_t)((0x100000000ull + (unsigned)cps - 1) / (unsigned)cps);
+          r = (int)__umulhi((uint32_t)ff, inv_cps);
+          const int cp = ff - r * cps;
+          ol = cp >> 2, pair = cp & 3;
+        }
         int off = (int)kOOB, lds = -1;
         if constexpr (XM == 2) {
           const int b = b0 + r;
-          lds = (ol * PCH + 4 * r) * PB;
-          if (b < a.B) off = 16 * (b * a.Ci + g * Cig);
+          lds = (ol * PCH + 4 * r) * PB + 4 * pair;
+          if (b < a.B) off = 16 * (b * a.Ci + g * Cig + 2 * pair);
         } else if constexpr (XM == 1) {
           const int b = b0 + r;
           lds = (ol * PCH + r) * PB;
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
           const bool in = it_off[i] != (int)kOOB && oc < G8;  // octets past the end read zeros (their weights are zeros too)
           if constexpr (XM == 2) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < 2; ++c) {
               const float4 v = ldf4(r_x, in ? (uint32_t)(it_off[i] + 16 * (8 * oc + c)) : kOOB);
               xv[i][4 * c] = v.x, xv[i][4 * c + 1] = v.y, xv[i][4 * c + 2] = v.z, xv[i][4 * c + 3] = v.w;
             }
@@ -402,11 +411,15 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       for (int i = 0; i < PIT; ++i) {
         if ((i == 0 || wave_i0 + kProducers * i < n_items_w) && it_lds[i] >= 0) {
           char* const dst = Xt + it_lds[i];
-          if constexpr (XM == 2) {
+          if constexpr (XM == 2) {  // 2 channels x the plane's 4 pixels: one dword of each pixel's 16-byte slots
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
-              const float v[8] = {xv[i][px], xv[i][4 + px], xv[i][8 + px], xv[i][12 + px], xv[i][16 + px], xv[i][20 + px], xv[i][24 + px], xv[i][28 + px]};
-              store_px(dst + px * PB, v);
+              uint32_t h0, m0_, l0, h1, m1, l1;
+              split_pieces(xv[i][px], h0, m0_, l0);
+              split_pieces(xv[i][4 + px], h1, m1, l1);
+              *reinterpret_cast<uint32_t*>(dst + px * PB) = pack_hi16(h1, h0);
+              *reinterpret_cast<uint32_t*>(dst + px * PB + 16) = pack_hi16(m1, m0_);
+              if constexpr (NP == 3) *reinterpret_cast<uint32_t*>(dst + px * PB + 32) = pack_hi16(l1, l0);
             }
           } else if constexpr (XM == 3) {  // 4 pixels x 4 channels: half of each pixel's 16-byte slots
 #pragma unroll
