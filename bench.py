@@ -418,6 +418,9 @@ def main():
                     launches_per_step=nl, avg_launch_ms=round(tot["ms"] / nl, 4),
                     flop_per_step=tot["nom"], flop_executed=tot["exe"], flop_effective=tot["eff"],
                     layers_above_peak=over,
+                    bf16_pipe=(dict(note="split kernels issue 6 bf16 MFMAs per fp32-equivalent K16 step (odd tap counts: 10/9 more)",
+                                    kernel_issue_tflops=round(6 * dom_ach, 1), peak=PEAK_BF16_MFMA_TFLOPS, kernel_frac=round(6 * dom_ach / PEAK_BF16_MFMA_TFLOPS, 4))
+                               if "split" in dom_name else None),
                     note="fp32-equivalent FLOPs; frac = executed FLOPs (active taps only, channels padded to the kernel's quad) x S samples per launch / "
                          "event-measured launch time (per layer: median over the K steps) / the fp32-MFMA peak"
                          + ("; the contraction runs as bf16-split products on the bf16 matrix pipe with fp32 accumulation, so a figure above the fp32-MFMA peak is legitimate here" if bf16 else ""),

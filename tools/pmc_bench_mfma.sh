@@ -12,7 +12,7 @@ cnt = collections.Counter()
 for f in glob.glob(f"gpurun_out/pmc_mfma_{tag}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "fused_f" not in k:
+        if "fused_" not in k:
             continue
         k = re.sub(r"\(bt::FwdArgs\)|void bt::", "", k)
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
