@@ -152,7 +152,7 @@ def test_library_exports_every_declared_symbol():
     """include/bt_hip.h <-> libbtorch_hip.so: every declared entry point is exported (no compute call is made)."""
     from bayesian_torch_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "bt_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char \*)\s*\*?(bt_[a-z0-9_]+)\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|size_t|const char \*)\s*\*?(bt_[a-z0-9_]+)\(", hdr, flags=re.M))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in sorted(declared):
