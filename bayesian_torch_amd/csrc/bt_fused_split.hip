@@ -3,7 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "bt_fused_split.h"
+#include "bt_fused_split_quad.h"
 
 namespace bt {
 
@@ -130,14 +130,63 @@ static int launch_split_xm(FwdArgs& a, int mode, int xm, hipStream_t stream) {
   return launch_split_cfg<BM, 3, NPW, 0>(a, stream);
 }
 
+// Layers with <= 4 input channels per group (the ResNet stems): bt_fused_split_quad.h. Whole-image 512-wide tiles, output through
+// the LDS-staged read-out (optionally with the fused 3x3 / stride-2 max-pool, power-of-two pooled widths).
+template <bool POOL>
+static int launch_quad_cfg(FwdArgs& a, int mode, hipStream_t stream) {
+  constexpr int lds = split_lds_bytes<64, 512, 3>();
+  auto launch = [&](auto kern, const char* nm) -> int {
+    static bool flags[2][64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return set_error(BT_ERR_HIP_BASE, "fused forward (split): hipGetDevice failed");
+    if (!flags[mode == 2][dev]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return set_error(BT_ERR_HIP_BASE, "fused forward (split): cannot raise the dynamic LDS limit");
+      flags[mode == 2][dev] = true;
+    }
+    note_kernel(nm);
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.total_blocks), dim3(512), lds, stream, a);
+    return check_launch("fused forward (split, quad)");
+  };
+  // (the opt-in two-piece form is not instantiated for the stems: they run the exact split in every split mode)
+  return launch(fused_split_quad_kernel<3, POOL>, POOL ? "fused_split_quad_kernel<64,512,bf16x3,6 terms,pool=1>" : "fused_split_quad_kernel<64,512,bf16x3,6 terms,pool=0>");
+}
+
+static int launch_quad(FwdArgs& a, int mode, hipStream_t stream) {
+  if (a.pixel_major || a.T > 64 || !a.out_vec4 || a.HoWo > 512 || a.HoWo < 2) return 1;
+  int nh, nw, dys, dxs;
+  tap_window(a.KH, a.DH, a.SH, a.PH, a.H, a.Ho, false, &nh, &dys);
+  tap_window(a.KW, a.DW, a.SW, a.PW, a.W, a.Wo, false, &nw, &dxs);
+  const long long PHt = (long long)(a.Ho - 1) * (dys ? a.SH : 1) + dys + 1, PWt = (long long)(a.Wo - 1) * (dxs ? a.SW : 1) + dxs + 1;
+  int NI = 512 / a.HoWo;
+  if (NI > a.B) NI = a.B;
+  constexpr long long XCAP = kQuadXBytes / 24;
+  while (NI > 1 && NI * PHt * PWt > XCAP) --NI;
+  if (NI * PHt * PWt > XCAP) return 1;
+  const long long n_bt = (a.B + NI - 1) / NI;
+  if ((double)a.M / ((double)n_bt * 512) < 0.75) return 1;   // the wide tile must be filled
+  if (a.ep_pool) {
+    const int Wp = a.ep_Wp;
+    if ((Wp & (Wp - 1)) != 0 || Wp < 4 || Wp > 16 || a.ep_res) return 1;
+  }
+  a.n_tiles = (a.Cog + 63) / 64;
+  a.t_NI = NI, a.t_R = a.Ho, a.t_Wt = a.Wo, a.n_bt = (int)n_bt, a.n_rt = 1, a.n_ct = 1, a.m_tiles = (int)n_bt;
+  const long long total = (long long)a.G * a.n_tiles * a.S * a.m_tiles;
+  if (total <= 0 || total > 0x7FFFFFFFll) return 1;
+  a.total_blocks = (int)total;
+  a.kl_slices = total < 256 ? (int)total : 256;
+  return a.ep_pool ? launch_quad_cfg<true>(a, mode, stream) : launch_quad_cfg<false>(a, mode, stream);
+}
+
 // Returns BT_OK when the launch was taken, 1 when this flavour does not apply (the caller runs the fp32 kernels), < 0 on error.
 int launch_split(FwdArgs& a, hipStream_t stream) {
   const int mode = contraction_mode();
   if (mode == 1) return 1;
-  // Reparameterization, on-chip draws, packed parameters, whole channel octets, at most 9 taps, 32-bit byte offsets
-  if (!a.mu_pk || (((uintptr_t)a.mu_pk | (uintptr_t)a.sig_pk) & 15u) || (a.Cig & 7) || a.T > 9 || a.ep_pool || a.w_elems >= (1ll << 29) ||
-      a.x_elems >= (1ll << 29))
-    return 1;
+  // Reparameterization, on-chip draws, packed parameters, 32-bit byte offsets
+  if (!a.mu_pk || (((uintptr_t)a.mu_pk | (uintptr_t)a.sig_pk) & 15u) || a.w_elems >= (1ll << 29) || a.x_elems >= (1ll << 29)) return 1;
+  if (a.Cig <= 4) return launch_quad(a, mode, stream);   // the stems
+  // whole channel octets, at most 9 taps, no fused pooling
+  if ((a.Cig & 7) || a.T > 9 || a.ep_pool) return 1;
   const int Mdom = a.pixel_major ? a.B : a.M;
   if (Mdom < 112) return 1;
   a.n_tiles = (a.Cog + 63) / 64;

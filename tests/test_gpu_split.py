@@ -201,3 +201,61 @@ def test_fp32_kernel_repeatability_on_a_padded_channel_chunk():
         assert torch.isfinite(out).all(), "non-finite output from " + kn
         first = out if first is None else first
         assert torch.equal(out, first)
+
+
+STEMS = {
+    "CIFAR ResNet stem 3->64 7x7 s2 on 32x32": (3, 64, (7, 7), 2, 3, 32, 32, 12, 2, False),
+    "4 channels, 5x5 s1, bias, 40 output channels": (4, 40, (5, 5), 1, 2, 16, 16, 6, 1, True),
+    "1 channel, 3x3": (1, 64, (3, 3), 1, 1, 16, 16, 4, 2, True),
+    "2 channels, 7x7 s2 on 64x64 (one image per tile)": (2, 64, (7, 7), 2, 3, 32, 32, 3, 1, False),
+}
+
+
+@pytest.mark.parametrize("name", list(STEMS))
+def test_stem_kernel_vs_c_oracle(name):
+    """<= 4 input channels: the quad flavour (bt_fused_split_quad.h: two taps per k-group, patch staged once, tap chunks)."""
+    from oracle import c_oracle as CO
+    from bayesian_torch_amd import functional as F
+    Ci, Co, k, st, pd, H, W, B, S, bias = STEMS[name]
+    g = torch.Generator().manual_seed(abs(hash(name)) % (1 << 31))
+    mu, rho = torch.randn(Co, Ci, *k, generator=g) * 0.1, torch.randn(Co, Ci, *k, generator=g) * 0.1 - 3
+    mb = torch.randn(Co, generator=g) * 0.1 if bias else None
+    rb = torch.randn(Co, generator=g) * 0.1 - 3 if bias else None
+    x = torch.randn(B, Ci, H, W, generator=g)                     # shared by the samples, like a model's input
+    conv = dict(stride=(st, st), padding=(pd, pd), dilation=(1, 1), groups=1)
+    out, kn = _run(mu, rho, mb, rb, x, conv, S, 0, shared=True)
+    assert "fused_split_quad_kernel" in kn, kn
+    out32, kn32 = _run(mu, rho, mb, rb, x, conv, S, 1, shared=True)
+    assert "split" not in kn32
+    dev = torch.device("cuda")
+    eps_w = F.rng_fill_normal(77, 2, 9, 5, 0, S, mu.shape, dev).cpu()
+    eps_b = F.rng_fill_normal(77, 2, 9, 5, 1, S, (Co,), dev).cpu() if bias else None
+    out, out32 = out.reshape((S, B) + tuple(out.shape[1:])).cpu(), out32.reshape((S, B) + tuple(out.shape[1:])).cpu()
+    for s in range(S):
+        ref = CO.reparam_fwd(x, mu, rho, eps_w[s], mb, rb, None if eps_b is None else eps_b[s], conv)
+        assert_close(out[s], ref, RTOL, ATOL, f"{name}[s={s}] quad vs C oracle")
+        scale = float(ref.abs().max())
+        e_split = float((out[s].double() - ref.double()).abs().max()) / scale
+        e_f32 = float((out32[s].double() - ref.double()).abs().max()) / scale
+        assert e_split <= 4.0 * e_f32 + 1.2e-7, (name, s, e_split, e_f32)
+    # launch-split independence
+    a, _ = _run(mu, rho, mb, rb, x, conv, 1, 0, sample0=5 + S - 1, shared=True)
+    assert torch.equal(a.cpu().reshape(out[S - 1].shape), out[S - 1])
+
+
+def test_stem_kernel_fused_maxpool():
+    """conv -> scale/shift -> ReLU -> MaxPool2d(3, 2, 1) in the quad kernel's output stage == max_pool2d of its unpooled launch."""
+    from bayesian_torch_amd import _lib
+    from bayesian_torch_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    mu, rho = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).cuda(), (torch.randn(64, 3, 7, 7, generator=g) * 0.1 - 3).cuda()
+    sc, sh = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.3).cuda()
+    x = torch.randn(10, 3, 32, 32, generator=g).cuda()
+    conv = dict(stride=(2, 2), padding=(3, 3), dilation=(1, 1), groups=1)
+    kw = dict(conv=conv, S=3, seed=5, call=1, layer_id=4, sample0=0, packed=F.pack_params(mu, rho), post_scale=sc, post_shift=sh, relu=True)
+    pooled = F._fused_forward(x, mu, rho, pool=True, **kw)
+    assert pooled is not None and "fused_split_quad_kernel" in _lib.lib().bt_last_kernel_name().decode() and "pool=1" in _lib.lib().bt_last_kernel_name().decode()
+    full, _ = F.fused_forward(x, mu, rho, **kw)
+    assert "pool=0" in _lib.lib().bt_last_kernel_name().decode()
+    assert tuple(pooled[0].shape) == (30, 64, 8, 8)
+    assert torch.equal(pooled[0], torch.nn.functional.max_pool2d(full, 3, 2, 1))
