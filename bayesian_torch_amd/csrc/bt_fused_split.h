@@ -16,9 +16,11 @@
 //   * K order (canonical, independent of the tile): channels in OCTETS of 8; an MFMA step covers two (octet, active tap)
 //     entries -- lanes 0-31 hold the 8 channels of the first, lanes 32-63 of the second. nA > 1: the octet's taps in
 //     pairs (a0,a1), (a2,a3) ...; an odd last tap runs with an empty second half. nA == 1: consecutive octets in pairs.
-//   * x tile: the LDS patch of the fast kernel, but channel-last -- X[octet][patch pixel][piece][8 channels] bf16, 16*NP
-//     bytes per pixel, so an operand fragment (8 channels of one pixel, one piece) is ONE ds_read_b128 at
-//     pixel(lane) + tap offset(step, lane half), and the three pieces are immediates apart.
+//   * x tile: the LDS patch of the fast kernel, but channel-last and WITHOUT its zero halo -- X[octet][real patch pixel][piece]
+//     [8 channels] bf16, 16*NP bytes per pixel, so an operand fragment (8 channels of one pixel, one piece) is ONE
+//     ds_read_b128 and the three pieces are immediates apart. The byte address of every (column group, step) fragment of a
+//     lane is computed once per workgroup; a (lane, tap) pair that falls into the padding points at one shared zero pixel
+//     (same address in many lanes = a broadcast). 8x8 maps keep 64 instead of 100 pixels per image, 4x4 maps 16 of 36.
 //   * w tile: W[step][lane half][piece][row][8 channels] bf16 -- 16 consecutive rows cover all 64 banks.
 // Producers split every sampled weight and every staged activation once; consumers only read LDS and issue MFMAs.
 #pragma once
@@ -31,8 +33,8 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kSplitSteps = 5;  // MFMA K16-steps per barrier stage (9 taps of one octet = 5 steps)
 
 template <int BM>
-constexpr int split_xpo() {  // pixel-octets one x buffer holds (8 images of a 10x10 patch = 800; 16 of a 6x6 = 576): what 160 KB allow
-  return 1024;
+constexpr int split_xpo() {  // pixel-octet slots of one x buffer: 1024 patch pixels (what 160 KB allow) + the shared zero pixel
+  return 1025;
 }
 template <int BN, int NP>
 constexpr int split_w_bytes() { return kSplitSteps * 2 * NP * BN * 16; }
@@ -81,7 +83,6 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
   int4* const taptab = reinterpret_cast<int4*>(smem_c + 2 * (W_BYTES + X_BYTES));
   double* const red = reinterpret_cast<double*>(smem_c + 2 * (W_BYTES + X_BYTES) + kMaxTaps * 16);
   int* const misc = reinterpret_cast<int*>(red + 12);
-  int* const eofftab = misc + 8;  // [kSplitSteps][2]: x byte offset of the (octet, tap) entry of (step, lane half)
   (void)red;
 
   unsigned long long* const dbg_ = kStamps ? a.dbg : nullptr;  // stage stamps: diagnostic build only (make STAMPS=1)
@@ -158,8 +159,15 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
   const int ps_h = (dymax == dymin) ? 1 : a.SH, gs_h = (dymax == dymin) ? a.SH : 1;
   const int ps_w = (dxmax == dxmin) ? 1 : a.SW, gs_w = (dxmax == dxmin) ? a.SW : 1;
   const int PHt = (t_R - 1) * ps_h + (dymax - dymin) + 1, PWt = (t_Wt - 1) * ps_w + (dxmax - dxmin) + 1;
-  const int PIMG = PHt * PWt, PCH = t_NI * PIMG;  // patch pixels of one image / of one octet plane (host: PCH <= XPO)
   const int x_lo = w0 * a.SW - a.PW + dxmin, y_lo = r0 * a.SH - a.PH + dymin;
+  // Only the patch rows / columns that exist in the image are stored: grid rows k (input row y_lo + k * gs_h) with
+  // kmin_h <= k <= kmax_h, likewise columns. (PHt x PWt is the full window, halo included.)
+  const int kmin_h = y_lo < 0 ? (-y_lo + gs_h - 1) / gs_h : 0, kmin_w = x_lo < 0 ? (-x_lo + gs_w - 1) / gs_w : 0;
+  int kmax_h = a.H - 1 - y_lo >= 0 ? (a.H - 1 - y_lo) / gs_h : -1, kmax_w = a.W - 1 - x_lo >= 0 ? (a.W - 1 - x_lo) / gs_w : -1;
+  kmax_h = kmax_h < PHt - 1 ? kmax_h : PHt - 1, kmax_w = kmax_w < PWt - 1 ? kmax_w : PWt - 1;
+  const int NYR = kmax_h >= kmin_h ? kmax_h - kmin_h + 1 : 0, NXR = kmax_w >= kmin_w ? kmax_w - kmin_w + 1 : 0;
+  const int PIMG = NYR * NXR, PCH = t_NI * PIMG;  // real patch pixels of one image / of one octet plane (host: NO * PCH < XPO)
+  constexpr int ZOFF = X_BYTES - PB;                // the shared zero pixel: last slot of each x buffer, never written
   const int SPO = (nA + 1) >> 1;
   int NO;
   if (nA <= 1) {
@@ -167,25 +175,12 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
   } else {
     NO = kSplitSteps / SPO;
   }
-  while (NO > 1 && NO * PCH > XPO) --NO;
+  while (NO > 1 && NO * PCH > XPO - 1) --NO;
   if (nA <= 1 && NO > 1) NO &= ~1;  // whole pairs per stage
   if (NO > G8) NO = G8;             // (a single stage may then end in a half-empty pair: the W slot holds zeros)
   const int NQ = NO * (nA > 0 ? nA : 1);                       // (octet, tap) entries of a full stage
   const int NSTEP = nA <= 1 ? (NO + 1) >> 1 : NO * SPO;        // MFMA steps of a full stage
   const int NS = nA ? (G8 + NO - 1) / NO : 0;
-  if (tid < 2 * kSplitSteps) {  // entry offsets (bytes into an x buffer) per (step, lane half)
-    const int st_ = tid >> 1, hf = tid & 1;
-    int off = 0;  // dead entries read entry 0 (valid data) against zero weights
-    if (nA == 1) {
-      const int ol = 2 * st_ + hf;
-      if (ol < NO) off = ol * PCH * PB + ((taptab[0].y - dymin) * PWt + (taptab[0].z - dxmin)) * PB;
-    } else if (nA > 1) {
-      const int ol = st_ / SPO, ai = 2 * (st_ - ol * SPO) + hf;
-      if (ol < NO && ai < nA) off = ol * PCH * PB + ((taptab[ai].y - dymin) * PWt + (taptab[ai].z - dxmin)) * PB;
-      else if (ol < NO) off = ol * PCH * PB + ((taptab[0].y - dymin) * PWt + (taptab[0].z - dxmin)) * PB;
-    }
-    eofftab[tid] = off;
-  }
   // The W slots no unit ever writes (second half of an odd tap count's last step) must hold zeros, and an x entry that is
   // multiplied by such zeros (or by the zero weights of octets past the end) must at least be finite: clear everything once.
   for (int i = tid; i < 2 * (W_BYTES + X_BYTES) / 16; i += kThreadsAll) reinterpret_cast<uint4*>(smem_c)[i] = make_uint4(0, 0, 0, 0);
@@ -207,7 +202,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
   float* const out_s = a.out + (long long)s * a.out_elems;
   const float* const res_s = a.ep_res ? a.ep_res + (long long)s * a.ep_res_stride : nullptr;
   const bool relu = a.ep_relu != 0;
-  __syncthreads();  // eofftab, cleared W buffers
+  __syncthreads();  // cleared buffers
 
   // Read-out of one staged pass of the output tile (SROWS channels) by every wave (see the output stage below).
   auto readout_quads = [&](int pass, int t0) {
@@ -283,18 +278,17 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     const int wave_u0 = __builtin_amdgcn_readfirstlane(ptid & ~63);
     // x items of this thread (see XM above): global byte offset of the item at octet 0, LDS byte offset inside an x buffer,
     // octet inside the stage.
-    constexpr int PIT = XM == 3 ? (XPO / 2 + kProducers - 1) / kProducers : (XPO + kProducers - 1) / kProducers;
+    constexpr int PIT = XM == 3 ? ((XPO - 1) / 2 + kProducers - 1) / kProducers : (XPO - 1 + kProducers - 1) / kProducers;   // (XPO - 1 patch slots + the zero pixel)
     constexpr int XV = XM == 3 ? 16 : 8;
     int it_off[PIT], it_lds[PIT], it_ol[PIT];
     // real input rows of the patch and 16-byte quads per row (XM 3)
-    const int ylo_r = y_lo > 0 ? y_lo : 0, yhi_r = (y_lo + PHt < a.H) ? y_lo + PHt : a.H;
-    const int nyr = yhi_r > ylo_r ? yhi_r - ylo_r : 0, W4 = a.W >> 2;
+    const int ylo_r = y_lo + kmin_h * gs_h, nyr = NYR, W4 = a.W >> 2;   // (XM 3: gs == 1, the stored columns are the whole row: NXR == W)
     const int per_oct = XM == 2 ? 4 * t_NI : XM == 3 ? 2 * t_NI * nyr * W4 : PCH;   // XM 2: (image, channel pair) items
     const int n_items = NO * per_oct;
     {
       const uint32_t inv_per = per_oct > 1 ? (uint32_t)((0x100000000ull + (unsigned)per_oct - 1) / (unsigned)per_oct) : 0u;
-      const uint32_t inv_pimg = (uint32_t)((0x100000000ull + (unsigned)PIMG - 1) / (unsigned)PIMG);
-      const uint32_t inv_pw = (uint32_t)((0x100000000ull + (unsigned)PWt - 1) / (unsigned)PWt);
+      const uint32_t inv_pimg = PIMG > 0 ? (uint32_t)((0x100000000ull + (unsigned)PIMG - 1) / (unsigned)PIMG) : 0u;
+      const uint32_t inv_pw = NXR > 0 ? (uint32_t)((0x100000000ull + (unsigned)NXR - 1) / (unsigned)NXR) : 0u;
       const int qpi = nyr * W4;  // quads per image (XM 3)
       const uint32_t inv_qpi = qpi > 1 ? (uint32_t)((0x100000000ull + (unsigned)qpi - 1) / (unsigned)qpi) : 0u;
       const uint32_t inv_w4 = W4 > 1 ? (uint32_t)((0x100000000ull + (unsigned)W4 - 1) / (unsigned)W4) : 0u;
@@ -333,16 +327,16 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
           const int yr = W4 <= 1 ? rem : (int)__umulhi((uint32_t)rem, inv_w4);
           const int xq = rem - yr * W4;
           const int b = b0 + img, y = ylo_r + yr, x = 4 * xq;
-          lds = (ol * PCH + img * PIMG + (y - y_lo) * PWt + (x - x_lo)) * PB + hc * 8;
+          lds = (ol * PCH + img * PIMG + (y - ylo_r) * NXR + x) * PB + hc * 8;
           if (b < a.B) off = 4 * ((b * a.Ci + g * Cig + 4 * hc) * a.HW + y * a.W + x);
         } else {
-          const int img = PIMG == 1 ? r : (int)__umulhi((uint32_t)r, inv_pimg);
+          const int img = PIMG <= 1 ? r : (int)__umulhi((uint32_t)r, inv_pimg);
           const int rem = r - img * PIMG;
-          const int yy = PWt == 1 ? rem : (int)__umulhi((uint32_t)rem, inv_pw);
-          const int xx = rem - yy * PWt;
-          const int b = b0 + img, y = y_lo + yy * gs_h, x = x_lo + xx * gs_w;
+          const int yy = NXR <= 1 ? rem : (int)__umulhi((uint32_t)rem, inv_pw);
+          const int xx = rem - yy * NXR;
+          const int b = b0 + img, y = y_lo + (yy + kmin_h) * gs_h, x = x_lo + (xx + kmin_w) * gs_w;   // a real pixel by construction
           lds = (ol * PCH + r) * PB;
-          if (b < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) off = 4 * ((b * a.Ci + g * Cig) * a.HW + y * a.W + x);  // else: halo, reads 0
+          if (b < a.B) off = 4 * ((b * a.Ci + g * Cig) * a.HW + y * a.W + x);
         }
         it_off[i] = off;
         it_lds[i] = f < n_items ? lds : -1;
@@ -568,18 +562,35 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         }
       }
     };
-    // x byte offset of this lane's output pixel per 32-wide column group, and of the entries of this lane half
-    int colb[TM];
+    // Byte address (inside an x buffer) of this lane's operand fragment for every (column group, step): the (octet, tap) entry
+    // of (step, lane half) applied to the lane's output pixel -- or the shared zero pixel when that tap falls into the padding
+    // for this pixel (or the column / the entry is dead: dead entries meet zero weights, any finite data will do).
+    int xaddr[TM][kSplitSteps];
+    {
+      int pimg[TM], pyb[TM], pxb[TM];
+      bool live[TM];
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int ml = wm * WTM + j * 32 + li;
-      int b, ho, wo;
-      const bool live = col_decode(ml, b, ho, wo);
-      colb[j] = live ? ((b - b0) * PIMG + (ho - r0) * ps_h * PWt + (wo - w0) * ps_w) * PB : 0;
+      for (int j = 0; j < TM; ++j) {
+        int b, ho, wo;
+        live[j] = col_decode(wm * WTM + j * 32 + li, b, ho, wo);
+        pimg[j] = (b - b0) * PIMG, pyb[j] = (ho - r0) * ps_h, pxb[j] = (wo - w0) * ps_w;
+      }
+#pragma unroll
+      for (int q = 0; q < kSplitSteps; ++q) {
+        int ol, ai;  // entry of (step q, this lane half)
+        if (nA <= 1) ol = 2 * q + lh, ai = 0;
+        else ol = q / SPO, ai = 2 * (q - ol * SPO) + lh;
+        const bool ent = nA > 0 && ol < NO && ai < nA;
+        const int4 e = taptab[ent ? ai : 0];
+        const int ty = (dymax == dymin) ? 0 : e.y - dymin, tx = (dxmax == dxmin) ? 0 : e.z - dxmin;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int yy = pyb[j] + ty, xx = pxb[j] + tx;  // position on the full patch grid
+          const bool ok = ent && live[j] && yy >= kmin_h && yy <= kmax_h && xx >= kmin_w && xx <= kmax_w;
+          xaddr[j][q] = ok ? (ol * PCH + pimg[j] + (yy - kmin_h) * NXR + (xx - kmin_w)) * PB : ZOFF;
+        }
+      }
     }
-    int eoff[kSplitSteps];
-#pragma unroll
-    for (int q = 0; q < kSplitSteps; ++q) eoff[q] = eofftab[2 * q + lh];
     int wlq[kSplitSteps];  // this lane's row slot inside the (step, half) plane: swizzled like the producers' writes
 #pragma unroll
     for (int q = 0; q < kSplitSteps; ++q) wlq[q] = lh * W_HALF + (li ^ ((2 * q + lh) & 7)) * 16;
@@ -614,7 +625,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
             for (int p = 0; p < NP; ++p) wf[i][p] = *reinterpret_cast<const bf16x8*>(Wt + wlq[q] + q * W_STEP + p * W_PIECE + i * 32 * 16);
 #pragma unroll
           for (int j = 0; j < TM; ++j) {
-            const char* const px = Xt + colb[j] + eoff[q];
+            const char* const px = Xt + xaddr[j][q];
             bf16x8 xf[NP];
 #pragma unroll
             for (int p = 0; p < NP; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(px + 16 * p);

@@ -21,16 +21,18 @@ static int contraction_mode() {
 
 // Extent of the window of taps that can meet data along one axis (the kernel's own rule: bt_fused_split.h), for the whole
 // output axis or -- pixel-major tiles prune per pixel -- the widest window of any single output position.
-static void tap_window(int K, int D, int S, int P, int In, int Out, bool per_pixel, int* n_act, int* extent) {
-  int best_n = 0, best_ext = 0;
+static void tap_window(int K, int D, int S, int P, int In, int Out, bool per_pixel, int* n_act, int* extent, int* n_min = nullptr) {
+  int best_n = 0, best_ext = 0, least_n = 1 << 30;
   if (per_pixel) {
     for (int o = 0; o < Out; ++o) {
       int lo = 1 << 30, hi = -1, n = 0;
       for (int k = 0; k < K; ++k)
         if ((unsigned)(o * S - P + k * D) < (unsigned)In) lo = k * D < lo ? k * D : lo, hi = k * D > hi ? k * D : hi, ++n;
       if (n > best_n) best_n = n;
+      if (n < least_n) least_n = n;
       if (hi - lo > best_ext) best_ext = hi - lo;
     }
+    if (n_min) *n_min = least_n;
   } else {
     int lo = 1 << 30, hi = -1;
     for (int k = 0; k < K; ++k) {
@@ -59,16 +61,20 @@ static bool split_rows_cover(const FwdArgs& a) {
 // fit XPO pixels. Fills the tile fields and returns the tile's live columns (0: does not fit).
 template <int BM>
 static int split_geometry(FwdArgs& a) {
-  int nh, nw, dys, dxs;
-  tap_window(a.KH, a.DH, a.SH, a.PH, a.H, a.Ho, a.pixel_major != 0, &nh, &dys);
-  tap_window(a.KW, a.DW, a.SW, a.PW, a.W, a.Wo, a.pixel_major != 0, &nw, &dxs);
+  int nh, nw, dys, dxs, nh_min = 0, nw_min = 0;
+  tap_window(a.KH, a.DH, a.SH, a.PH, a.H, a.Ho, a.pixel_major != 0, &nh, &dys, &nh_min);
+  tap_window(a.KW, a.DW, a.SW, a.PW, a.W, a.Wo, a.pixel_major != 0, &nw, &dxs, &nw_min);
   // One active tap: the canonical K order pairs consecutive octets in one MFMA step, so a stage has to hold TWO octet planes
-  // whatever the tile (otherwise the pairing, and with it the rounding, would depend on the tile choice). Pixel-major tiles can
-  // meet one-tap pixels next to many-tap ones: same rule.
-  const bool one_tap = a.pixel_major || nh * nw <= 1;
-  const long long XPO = one_tap ? split_xpo<BM>() / 2 : split_xpo<BM>();
+  // whatever the tile (otherwise the pairing, and with it the rounding, would depend on the tile choice). Pixel-major tiles
+  // prune per pixel: the rule applies when some pixel is left with a single tap.
+  const bool one_tap = a.pixel_major ? nh_min * nw_min <= 1 : nh * nw <= 1;
+  const long long XPO = one_tap ? (split_xpo<BM>() - 1) / 2 : split_xpo<BM>() - 1;   // (one slot is the shared zero pixel)
   auto fits = [&](int NI, int R, int Wt) {
-    const long long PHt = (long long)(R - 1) * (dys ? a.SH : 1) + dys + 1, PWt = (long long)(Wt - 1) * (dxs ? a.SW : 1) + dxs + 1;
+    // the patch stores only pixels that exist: at most the window's rows / columns, at most the image's (on the patch grid)
+    long long PHt = (long long)(R - 1) * (dys ? a.SH : 1) + dys + 1, PWt = (long long)(Wt - 1) * (dxs ? a.SW : 1) + dxs + 1;
+    const long long rows_max = dys ? a.H : (a.H - 1) / a.SH + 1, cols_max = dxs ? a.W : (a.W - 1) / a.SW + 1;
+    if (PHt > rows_max) PHt = rows_max;
+    if (PWt > cols_max) PWt = cols_max;
     return NI * PHt * PWt <= XPO;
   };
   int NI, R, Wt;

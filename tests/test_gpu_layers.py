@@ -331,9 +331,10 @@ def test_fused_maxpool_output_stage(Ci, Co, k, st, pd, H, W, B, flip, fusable):
     packed = F.pack_params(cu(mu), cu(rho))
     kw = dict(flip=flip, conv=conv, S=S, seed=seed, call=call, layer_id=lid, sample0=s0, packed=packed, post_scale=cu(sc), post_shift=cu(sh), relu=True)
     direct = F._fused_forward(cu(x), cu(mu), cu(rho), cu(mb), cu(rb), pool=True, **kw)
+    pooled_on_split = "split" in _lib.lib().bt_last_kernel_name().decode()      # (stems: the quad flavour pools too)
     assert (direct is not None) == fusable, "fusability of this geometry changed"
     out, _ = F.fused_forward(cu(x), cu(mu), cu(rho), cu(mb), cu(rb), pool=True, **kw)
-    _lib.lib().bt_set_contraction(1)       # the pooled output stage lives in the fp32-MFMA kernels: compare like with like
+    _lib.lib().bt_set_contraction(0 if (pooled_on_split and direct is not None) else 1)       # compare like with like: same contraction flavour as the pooled launch
     try:
         full, _ = F.fused_forward(cu(x), cu(mu), cu(rho), cu(mb), cu(rb), **kw)
     finally:
