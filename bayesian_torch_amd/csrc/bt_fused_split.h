@@ -239,8 +239,9 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     }
   };
 
+  const int prio_mode = dbg_ ? (int)dbg_[200] : 0;  // diagnostic build: 0 producers first (product), 1 none, 2 consumers first
   if (producer) {
-    __builtin_amdgcn_s_setprio(3);
+    if (prio_mode == 0) __builtin_amdgcn_s_setprio(3);
     // =================================================== PRODUCERS ===========================================================
     // Weight unit u = (channel quad cq of the octet, row n, entry q = (octet ol, tap slot ai)): 4 sampled weights = one Philox
     // block. u = ptid + 256 i -> cq = u & 1, n = (u >> 1) % BN, q = (u >> 1) / BN: consecutive lanes fill one 16-byte LDS slot
@@ -602,6 +603,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (prio_mode == 2) __builtin_amdgcn_s_setprio(3);
 
     const bool cstamp = dbg_ && blockIdx.x == 0 && tid == 0;
     __syncthreads();  // stage 0 staged
@@ -615,31 +617,53 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         const int no_l = G8 - st * NO;
         nstep = nA <= 1 ? (no_l + 1) >> 1 : no_l * SPO;
       }
-#pragma unroll
-      for (int q = 0; q < kSplitSteps; ++q) {
-        if (q < nstep) {  // uniform
-          bf16x8 wf[TN][NP];
+      // (step, column group) units in a software pipeline: the fragments of unit u+1 (and, at a step's last unit, the next
+      // step's weight fragments) are read into the other register set BEFORE the 2*terms MFMAs of unit u, so an LDS round
+      // trip never sits between two MFMAs; only the first unit behind the stage barrier waits for its reads.
+      {
+        bf16x8 wf[2][TN][NP], xf[2][NP];
+        auto read_w = [&](int q) {
 #pragma unroll
           for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) wf[i][p] = *reinterpret_cast<const bf16x8*>(Wt + wlq[q] + q * W_STEP + p * W_PIECE + i * 32 * 16);
+            for (int p = 0; p < NP; ++p)
+              wf[q & 1][i][p] = *reinterpret_cast<const bf16x8*>(Wt + wlq[q] + q * W_STEP + p * W_PIECE + i * 32 * 16);
+        };
+        auto read_x = [&](int u) {
+          const char* const px = Xt + xaddr[u % TM][u / TM];
 #pragma unroll
-          for (int j = 0; j < TM; ++j) {
-            const char* const px = Xt + xaddr[j][q];
-            bf16x8 xf[NP];
+          for (int p = 0; p < NP; ++p) xf[u & 1][p] = *reinterpret_cast<const bf16x8*>(px + 16 * p);
+        };
+        read_w(0);
+        read_x(0);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(px + 16 * p);
+        for (int q = 0; q < kSplitSteps; ++q) {
+          if (q < nstep) {  // uniform
 #pragma unroll
-            for (int i = 0; i < TN; ++i) {
-              // D[pixel][channel]: x is the A operand, W the B operand; terms in decreasing weight
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[i][0], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[i][1], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], wf[i][0], acc[i][j], 0, 0, 0);
-              if constexpr (NP == 3) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[i][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], wf[i][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[2], wf[i][0], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TM; ++j) {
+              const int u = q * TM + j;
+              if (j + 1 < TM) {
+                read_x(u + 1);
+              } else if (q + 1 < kSplitSteps) {
+                if (q + 1 < nstep) {
+                  read_x(u + 1);
+                  read_w(q + 1);
+                }
               }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int i = 0; i < TN; ++i) {
+                // D[pixel][channel]: x is the A operand, W the B operand; terms in decreasing weight
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][0], wf[q & 1][i][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][0], wf[q & 1][i][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][1], wf[q & 1][i][0], acc[i][j], 0, 0, 0);
+                if constexpr (NP == 3) {
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][0], wf[q & 1][i][2], acc[i][j], 0, 0, 0);
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][1], wf[q & 1][i][1], acc[i][j], 0, 0, 0);
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][2], wf[q & 1][i][0], acc[i][j], 0, 0, 0);
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
             }
           }
         }

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bayesian_torch_amd import _lib, functional as F
 sys.argv = [sys.argv[0]] + sys.argv[1:]
 import argparse
-ap = argparse.ArgumentParser(); ap.add_argument("--shape", default="layer1"); ap.add_argument("--S", type=int, default=32); ap.add_argument("--B", type=int, default=128); ap.add_argument("--sigma", action="store_true"); ap.add_argument("--noprio", action="store_true"); ap.add_argument("--pool", action="store_true")
+ap = argparse.ArgumentParser(); ap.add_argument("--shape", default="layer1"); ap.add_argument("--S", type=int, default=32); ap.add_argument("--B", type=int, default=128); ap.add_argument("--sigma", action="store_true"); ap.add_argument("--noprio", action="store_true"); ap.add_argument("--prio", type=int, default=0); ap.add_argument("--pool", action="store_true")
 a = ap.parse_args()
 SH = {"conv1": (3, 64, 7, 2, 3, 32), "layer1": (64, 64, 3, 1, 1, 8), "layer2": (128, 128, 3, 1, 1, 4), "layer3": (256, 256, 3, 1, 1, 2), "layer4": (512, 512, 3, 1, 1, 1), "ds2": (64, 128, 1, 2, 0, 8), "l2s": (64, 128, 3, 2, 1, 8), "ds4": (256, 512, 1, 2, 0, 2)}
 pri = None
@@ -18,6 +18,7 @@ x = torch.randn(a.S * a.B, Ci, H, H, device=dev)
 conv = dict(stride=(st, st), padding=(pd, pd), dilation=(1, 1), groups=1)
 buf = torch.zeros(256, dtype=torch.int64, device=dev)
 if a.noprio: buf[200] = 1
+if a.prio: buf[200] = a.prio
 L = _lib.lib(); L.bt_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]; L.bt_debug_set_stamp_buffer.restype = None
 for i in range(3):
     F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=i, layer_id=3)
@@ -26,6 +27,13 @@ pri = (torch.zeros_like(mu), torch.ones_like(mu), None, None)
 F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=9, layer_id=3, packed=(F.pack_params(mu, rho) if a.sigma else None), pool=a.pool, relu=a.pool, priors=pri, want_kl=True)
 print(L.bt_last_kernel_name().decode())
 torch.cuda.synchronize()
+pk = F.pack_params(mu, rho) if a.sigma else None
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for i in range(20):
+    F.fused_forward(x, mu, rho, conv=conv, S=a.S, shared_x=False, seed=1, call=10 + i, layer_id=3, packed=pk, pool=a.pool, relu=a.pool, priors=pri, want_kl=True)
+e1.record(); torch.cuda.synchronize()
+print("avg launch (prio mode %d): %.1f us" % (int(buf[200]), e0.elapsed_time(e1) * 50))
 L.bt_debug_set_stamp_buffer(None)
 t = buf.cpu().tolist()
 t0 = t[0]
