@@ -32,17 +32,19 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kSplitSteps = 5;  // MFMA K16-steps per barrier stage (9 taps of one octet = 5 steps)
 
-template <int BM>
+// FLIP (Flipout): two weight images per stage (mu and sigma*eps) and a fourth 16-byte piece per x pixel (the sign masks of
+// its 8 channels), which leaves room for 301 patch pixels.
+template <int BM, bool FLIP = false>
 constexpr int split_xpo() {  // pixel-octet slots of one x buffer: 1024 patch pixels (what 160 KB allow) + the shared zero pixel
-  return 1025;
+  return FLIP ? 302 : 1025;
 }
-template <int BN, int NP>
-constexpr int split_w_bytes() { return kSplitSteps * 2 * NP * BN * 16; }
-template <int BM, int NP>
-constexpr int split_x_bytes() { return split_xpo<BM>() * NP * 16; }
+template <int BN, int NP, bool FLIP = false>
+constexpr int split_w_bytes() { return (FLIP ? 2 : 1) * kSplitSteps * 2 * NP * BN * 16; }
+template <int BM, int NP, bool FLIP = false>
+constexpr int split_x_bytes() { return split_xpo<BM, FLIP>() * (NP + (FLIP ? 1 : 0)) * 16; }
 constexpr int kSplitMiscBytes = kMaxTaps * 16 + 96 + 32 + 64;
-template <int BN, int BM, int NP>
-constexpr int split_lds_bytes() { return 2 * (split_w_bytes<BN, NP>() + split_x_bytes<BM, NP>()) + kSplitMiscBytes; }
+template <int BN, int BM, int NP, bool FLIP = false>
+constexpr int split_lds_bytes() { return 2 * (split_w_bytes<BN, NP, FLIP>() + split_x_bytes<BM, NP, FLIP>()) + kSplitMiscBytes; }
 
 // fp32 -> bf16 pieces by truncation, as fp32 bit patterns whose upper halves are the pieces
 __device__ __forceinline__ void split_pieces(float v, uint32_t& h, uint32_t& m, uint32_t& l) {
@@ -65,16 +67,26 @@ __device__ __forceinline__ uint32_t pack_hi16(uint32_t hi, uint32_t lo) {  // (h
 //      consecutive lanes take consecutive channels, so a wave's loads cover whole 256-byte pieces of an image.
 //   3: stride-1 tiles of whole rows with W % 4 == 0: item = (4 consecutive input pixels, half an octet): 16-byte row pieces;
 //      the zero halo of the patch is never written (the buffers are cleared once).
-template <int BN, int BM, int NP, int NPW, int XM>
+//
+// FLIP: the Flipout forward  out = x*mu + s_out o ((x o s_in) * (sigma o eps))  (flipout_layers.py:conv / linear forward): two
+// contractions that share the x pieces. The producers stage mu and sigma*eps as two weight images and, next to the pieces of
+// every x pixel, the sign masks of its 8 channels (bit 15 of each bf16 lane; same hash stream as the fp32 kernels); a consumer
+// issues the 6 terms of x*mu, flips the sign bits of its x fragments in registers (-(h+m+l) = -h-m-l: the split of -v is the
+// negated split of v), and issues the 6 terms of (x o s_in)*(sigma*eps) into the second accumulator set. 4 consumer waves of
+// 32 channels x 128 pixels each (2 x 2), BM = 256. s_out meets the second set in the read-out.
+template <int BN, int BM, int NP, int NPW, int XM, bool FLIP = false>
 __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdArgs a) {
   static_assert(BN == 64 && (BM == 512 || BM == 256 || BM == 128), "tile shapes of this flavour");
+  static_assert(!FLIP || (BM == 256 && NP == 3 && (XM == 0 || XM == 3)), "Flipout: the 64 x 256 tile, exact split");
   constexpr int kProducers = 64 * NPW, kThreadsAll = 256 + kProducers;
-  constexpr int CWM = 4, WTM = BM / CWM, TN = BN / 32, TM = WTM / 32;
-  constexpr int PB = 16 * NP;  // bytes per (pixel, octet) of the x patch
-  constexpr int W_BYTES = split_w_bytes<BN, NP>(), X_BYTES = split_x_bytes<BM, NP>(), XPO = split_xpo<BM>();
+  constexpr int CWM = FLIP ? 2 : 4, CWN = 4 / CWM, WTM = BM / CWM, TN = BN / CWN / 32, TM = WTM / 32;
+  constexpr int NOP = FLIP ? 2 : 1;            // weight operands (images per stage) = accumulator sets
+  constexpr int PB = 16 * (NP + (FLIP ? 1 : 0));  // bytes per (pixel, octet) of the x patch
+  constexpr int W_BYTES = split_w_bytes<BN, NP, FLIP>(), W_OP = W_BYTES / NOP, X_BYTES = split_x_bytes<BM, NP, FLIP>(), XPO = split_xpo<BM, FLIP>();
   constexpr int W_STEP = 2 * NP * BN * 16, W_HALF = NP * BN * 16, W_PIECE = BN * 16;
   // output staging: all BN channels in one pass when the operand buffers are large enough, else 32 at a time
-  constexpr int SROWS = ((4 * BN + BN * (BM + 4)) * 4 <= 2 * (W_BYTES + X_BYTES)) ? BN : 32, NPASS = BN / SROWS;
+  constexpr int SROWS = ((4 * BN + NOP * BN * (BM + 4)) * 4 <= 2 * (W_BYTES + X_BYTES)) ? BN : 32, NPASS = BN / SROWS;
+  static_assert(!FLIP || NPASS == 1, "Flipout stages both accumulator sets in one pass");
 
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   char* const wbuf = smem_c;                  // [2][W_BYTES]
@@ -90,7 +102,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
   const bool producer = wave >= 4;
   const int ptid = producer ? tid - 256 : tid;
   const int li = lane & 31, lh = lane >> 5;
-  const int wm = wave & 3;
+  const int wm = wave & (CWM - 1), wn = (wave & 3) / CWM;  // consumer wave: column block, row block
 
   int L = xcd_remap(blockIdx.x, a.total_blocks);
   const int mt = __builtin_amdgcn_readfirstlane(L % a.m_tiles);
@@ -122,6 +134,14 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
   key_w.seed_hi = a.seed_hi;
   key_w.call = a.call + (a.call_base ? __builtin_nontemporal_load(a.call_base) : 0u);
   key_w.layer_tensor = layer_tensor_word(a.layer_id, 0);
+  uint32_t skey_in = 0, skey_out = 0;  // Flipout sign streams (bt_fused_fwd.h)
+  if constexpr (FLIP) {
+    RngKey ks = key_w;
+    ks.layer_tensor = layer_tensor_word(a.layer_id, 2);
+    skey_in = sign_stream_key(ks, sample);
+    ks.layer_tensor = layer_tensor_word(a.layer_id, 3);
+    skey_out = sign_stream_key(ks, sample);
+  }
 
   // ---- active taps of this tile + their window (wave 0), as in the fast kernel -----------------------------------------
   if (wave == 0) {
@@ -196,6 +216,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
   auto ldf4 = [](const __amdgpu_buffer_rsrc_t& r, uint32_t byte_off) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0)); };
 
   float* const bias0 = smem;
+  float* const bias1 = smem + BN;  // Flipout: the sigma*eps part of the bias
   float* const osc = smem + 2 * BN;
   float* const osh = smem + 3 * BN;
   const bool kl_block = a.do_kl && (int)blockIdx.x < a.kl_slices;
@@ -223,6 +244,14 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         okq[u] = cr < NQD && mok && n0 + co_l < a.Cog;
         oidx[u] = okq[u] ? (uint32_t)(((bq * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hq) * a.Wo + wq) : 0u;
         v[u] = *reinterpret_cast<const float4*>(stage + row * SROW + 4 * m4);
+        if constexpr (FLIP) {  // second accumulator set x s_out, then the output-stage constants (the fp32 kernels' order)
+          const float4 d = *reinterpret_cast<const float4*>(stage + (SROWS + row) * SROW + 4 * m4);
+          const float sc = osc[co_l], sh = osh[co_l];
+          v[u].x = __fadd_rn(__fmul_rn(__fadd_rn(v[u].x, __fmul_rn(d.x, hash_sign(skey_out, oidx[u]))), sc), sh);
+          v[u].y = __fadd_rn(__fmul_rn(__fadd_rn(v[u].y, __fmul_rn(d.y, hash_sign(skey_out, oidx[u] + 1u))), sc), sh);
+          v[u].z = __fadd_rn(__fmul_rn(__fadd_rn(v[u].z, __fmul_rn(d.z, hash_sign(skey_out, oidx[u] + 2u))), sc), sh);
+          v[u].w = __fadd_rn(__fmul_rn(__fadd_rn(v[u].w, __fmul_rn(d.w, hash_sign(skey_out, oidx[u] + 3u))), sc), sh);
+        }
       }
       if (res_s) {
 #pragma unroll
@@ -392,20 +421,31 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         }
       }
     };
-    auto store_px = [&](char* dst, const float (&v)[8]) {  // 8 channels of one pixel -> NP pieces x 16 bytes
+    auto sign_bit = [&](uint32_t idx) -> uint32_t {  // bit 31 set: s_in = -1 (hash_sign's stream, element offset in the sample)
+      return __float_as_uint(hash_sign(skey_in, idx)) & 0x80000000u;
+    };
+    auto store_px = [&](char* dst, const float (&v)[8], uint32_t idx0, uint32_t cstride) {  // 8 channels of one pixel -> NP pieces x 16 bytes
       uint32_t ph[8], pm[8], pl[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) split_pieces(v[c], ph[c], pm[c], pl[c]);
+      if constexpr (FLIP) {
+        uint32_t sb[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sb[c] = sign_bit(idx0 + (uint32_t)c * cstride);
+        *reinterpret_cast<uint4*>(dst + 16 * NP) = make_uint4(pack_hi16(sb[1], sb[0]), pack_hi16(sb[3], sb[2]), pack_hi16(sb[5], sb[4]), pack_hi16(sb[7], sb[6]));
+      }
       *reinterpret_cast<uint4*>(dst) = make_uint4(pack_hi16(ph[1], ph[0]), pack_hi16(ph[3], ph[2]), pack_hi16(ph[5], ph[4]), pack_hi16(ph[7], ph[6]));
       *reinterpret_cast<uint4*>(dst + 16) = make_uint4(pack_hi16(pm[1], pm[0]), pack_hi16(pm[3], pm[2]), pack_hi16(pm[5], pm[4]), pack_hi16(pm[7], pm[6]));
       if constexpr (NP == 3)
         *reinterpret_cast<uint4*>(dst + 32) = make_uint4(pack_hi16(pl[1], pl[0]), pack_hi16(pl[3], pl[2]), pack_hi16(pl[5], pl[4]), pack_hi16(pl[7], pl[6]));
     };
-    auto store_x = [&](char* Xt) {
+    auto store_x = [&](char* Xt, int st) {
 #pragma unroll
       for (int i = 0; i < PIT; ++i) {
         if ((i == 0 || wave_i0 + kProducers * i < n_items_w) && it_lds[i] >= 0) {
           char* const dst = Xt + it_lds[i];
+          // Flipout: element offset (in the sample's x) of the item's first element -- the index of its sign
+          const uint32_t e0 = FLIP ? ((uint32_t)it_off[i] >> 2) + (uint32_t)(8 * (st * NO + it_ol[i])) * (uint32_t)a.HW : 0u;
           if constexpr (XM == 2) {  // 2 channels x the plane's 4 pixels: one dword of each pixel's 16-byte slots
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
@@ -425,10 +465,16 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
               *reinterpret_cast<uint2*>(dst + px * PB) = make_uint2(pack_hi16(ph[1], ph[0]), pack_hi16(ph[3], ph[2]));
               *reinterpret_cast<uint2*>(dst + px * PB + 16) = make_uint2(pack_hi16(pm[1], pm[0]), pack_hi16(pm[3], pm[2]));
               if constexpr (NP == 3) *reinterpret_cast<uint2*>(dst + px * PB + 32) = make_uint2(pack_hi16(pl[1], pl[0]), pack_hi16(pl[3], pl[2]));
+              if constexpr (FLIP) {
+                uint32_t sb[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sb[c] = sign_bit(e0 + (uint32_t)(c * a.HW + px));
+                *reinterpret_cast<uint2*>(dst + px * PB + 16 * NP) = make_uint2(pack_hi16(sb[1], sb[0]), pack_hi16(sb[3], sb[2]));
+              }
             }
           } else {
             const float v[8] = {xv[i][0], xv[i][1], xv[i][2], xv[i][3], xv[i][4], xv[i][5], xv[i][6], xv[i][7]};
-            store_px(dst, v);
+            store_px(dst, v, e0, XM == 1 ? 1u : (uint32_t)a.HW);
           }
         }
       }
@@ -456,19 +502,29 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
             const float m4[4] = {mu[i].x, mu[i].y, mu[i].z, mu[i].w}, s4[4] = {rs[i].x, rs[i].y, rs[i].z, rs[i].w};
             uint32_t wh[4], wm_[4], wl[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)  // masked units loaded zeros: w = 0 + 0 * eps = 0
-              split_pieces(__fadd_rn(m4[j], __fmul_rn(s4[j], ep[i][j])), wh[j], wm_[j], wl[j]);
+            for (int j = 0; j < 4; ++j)  // masked units loaded zeros: w = 0 + 0 * eps = 0.  Flipout: the mean alone
+              split_pieces(FLIP ? m4[j] : __fadd_rn(m4[j], __fmul_rn(s4[j], ep[i][j])), wh[j], wm_[j], wl[j]);
             if (l_off[i] >= 0) {
               char* const dst = Wt + l_off[i];
               *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(wh[1], wh[0]), pack_hi16(wh[3], wh[2]));
               *reinterpret_cast<uint2*>(dst + W_PIECE) = make_uint2(pack_hi16(wm_[1], wm_[0]), pack_hi16(wm_[3], wm_[2]));
               if constexpr (NP == 3) *reinterpret_cast<uint2*>(dst + 2 * W_PIECE) = make_uint2(pack_hi16(wl[1], wl[0]), pack_hi16(wl[3], wl[2]));
             }
+            if constexpr (FLIP) {  // second image: the perturbation sigma * eps
+#pragma unroll
+              for (int j = 0; j < 4; ++j) split_pieces(__fmul_rn(s4[j], ep[i][j]), wh[j], wm_[j], wl[j]);
+              if (l_off[i] >= 0) {
+                char* const dst = Wt + W_OP + l_off[i];
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(wh[1], wh[0]), pack_hi16(wh[3], wh[2]));
+                *reinterpret_cast<uint2*>(dst + W_PIECE) = make_uint2(pack_hi16(wm_[1], wm_[0]), pack_hi16(wm_[3], wm_[2]));
+                *reinterpret_cast<uint2*>(dst + 2 * W_PIECE) = make_uint2(pack_hi16(wl[1], wl[0]), pack_hi16(wl[3], wl[2]));
+              }
+            }
           }
         }
         if (pstamp && st == 3) dbg_[253] = __builtin_amdgcn_s_memtime();
         // ---- activations: this thread's items of the stage's NO octet planes, split on the way to LDS ----
-        store_x(Xt);
+        store_x(Xt, st);
         if (st + 1 < NS) load_x(st + 1), load_w(st + 1);  // next stage's loads: in flight across the barrier and the draws
       }
       if (pstamp && st < 60) dbg_[128 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
@@ -486,7 +542,11 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         philox_normal4(kb, sample, (uint32_t)(co >> 2), z);
         const int sel = co & 3;
         const float e = sel == 0 ? z[0] : sel == 1 ? z[1] : sel == 2 ? z[2] : z[3];
-        bv = __fadd_rn(a.mu_b[co], __fmul_rn(softplus(a.rho_b[co]), e));
+        const float dl = __fmul_rn(softplus(a.rho_b[co]), e);
+        bv = FLIP ? a.mu_b[co] : __fadd_rn(a.mu_b[co], dl);
+        if constexpr (FLIP) bias1[ptid] = dl;
+      } else if constexpr (FLIP) {
+        bias1[ptid] = 0.f;
       }
       bias0[ptid] = bv;
       const bool cv = a.ep_scale && co_g < a.Cog;
@@ -594,15 +654,17 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     }
     int wlq[kSplitSteps];  // this lane's row slot inside the (step, half) plane: swizzled like the producers' writes
 #pragma unroll
-    for (int q = 0; q < kSplitSteps; ++q) wlq[q] = lh * W_HALF + (li ^ ((2 * q + lh) & 7)) * 16;
+    for (int q = 0; q < kSplitSteps; ++q) wlq[q] = lh * W_HALF + (li ^ ((2 * q + lh) & 7)) * 16 + wn * TN * 32 * 16;
 
-    f32x16 acc[TN][TM];
+    f32x16 acc[NOP][TN][TM];
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int o = 0; o < NOP; ++o)
 #pragma unroll
-      for (int j = 0; j < TM; ++j)
+      for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[o][i][j][r] = 0.f;
     if (prio_mode == 2) __builtin_amdgcn_s_setprio(3);
 
     const bool cstamp = dbg_ && blockIdx.x == 0 && tid == 0;
@@ -621,18 +683,21 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       // step's weight fragments) are read into the other register set BEFORE the 2*terms MFMAs of unit u, so an LDS round
       // trip never sits between two MFMAs; only the first unit behind the stage barrier waits for its reads.
       {
-        bf16x8 wf[2][TN][NP], xf[2][NP];
+        constexpr int NXP = NP + (FLIP ? 1 : 0);  // x fragments per unit: the pieces (+ the sign masks)
+        bf16x8 wf[2][NOP][TN][NP], xf[2][NXP];
         auto read_w = [&](int q) {
 #pragma unroll
-          for (int i = 0; i < TN; ++i)
+          for (int o = 0; o < NOP; ++o)
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
-              wf[q & 1][i][p] = *reinterpret_cast<const bf16x8*>(Wt + wlq[q] + q * W_STEP + p * W_PIECE + i * 32 * 16);
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+              for (int p = 0; p < NP; ++p)
+                wf[q & 1][o][i][p] = *reinterpret_cast<const bf16x8*>(Wt + o * W_OP + wlq[q] + q * W_STEP + p * W_PIECE + i * 32 * 16);
         };
         auto read_x = [&](int u) {
           const char* const px = Xt + xaddr[u % TM][u / TM];
 #pragma unroll
-          for (int p = 0; p < NP; ++p) xf[u & 1][p] = *reinterpret_cast<const bf16x8*>(px + 16 * p);
+          for (int p = 0; p < NXP; ++p) xf[u & 1][p] = *reinterpret_cast<const bf16x8*>(px + 16 * p);
         };
         read_w(0);
         read_x(0);
@@ -652,15 +717,22 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
               }
               __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-              for (int i = 0; i < TN; ++i) {
-                // D[pixel][channel]: x is the A operand, W the B operand; terms in decreasing weight
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][0], wf[q & 1][i][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][0], wf[q & 1][i][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][1], wf[q & 1][i][0], acc[i][j], 0, 0, 0);
-                if constexpr (NP == 3) {
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][0], wf[q & 1][i][2], acc[i][j], 0, 0, 0);
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][1], wf[q & 1][i][1], acc[i][j], 0, 0, 0);
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][2], wf[q & 1][i][0], acc[i][j], 0, 0, 0);
+              for (int o = 0; o < NOP; ++o) {
+                if (o == 1) {  // Flipout: x o s_in -- flip the sign bits of every piece (the split of -v is the negated split of v)
+#pragma unroll
+                  for (int p = 0; p < NP; ++p) xf[u & 1][p] ^= xf[u & 1][NXP - 1];
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                  // D[pixel][channel]: x is the A operand, W the B operand; terms in decreasing weight
+                  acc[o][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][0], wf[q & 1][o][i][0], acc[o][i][j], 0, 0, 0);
+                  acc[o][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][0], wf[q & 1][o][i][1], acc[o][i][j], 0, 0, 0);
+                  acc[o][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][1], wf[q & 1][o][i][0], acc[o][i][j], 0, 0, 0);
+                  if constexpr (NP == 3) {
+                    acc[o][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][0], wf[q & 1][o][i][2], acc[o][i][j], 0, 0, 0);
+                    acc[o][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][1], wf[q & 1][o][i][1], acc[o][i][j], 0, 0, 0);
+                    acc[o][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u & 1][2], wf[q & 1][o][i][0], acc[o][i][j], 0, 0, 0);
+                  }
                 }
               }
               __builtin_amdgcn_sched_barrier(0);
@@ -680,28 +752,41 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     // ---- output stage + store (bt_fused_fast.h: lane = one channel, registers 4q..4q+3 = 4 consecutive positions) ----
     if (a.out_vec4) {
       constexpr int SROW = BM + 4;
-      static_assert((4 * BN + SROWS * SROW) * 4 <= 2 * (W_BYTES + X_BYTES), "output staging fits the operand buffers");
+      static_assert((4 * BN + NOP * SROWS * SROW) * 4 <= 2 * (W_BYTES + X_BYTES), "output staging fits the operand buffers");
       float* const stage = smem + 4 * BN;
-      float bsv[TN], scv[TN], shv[TN];
+      float bsv[TN], scv[TN], shv[TN], b1v[TN];
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
-        const int co_l = i * 32 + li;
+        const int co_l = (wn * TN + i) * 32 + li;
         bsv[i] = bias0[co_l], scv[i] = osc[co_l], shv[i] = osh[co_l];
+        b1v[i] = FLIP ? bias1[co_l] : 0.f;
       }
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         if (ps > 0) __syncthreads();  // the previous pass has been read out
 #pragma unroll
-        for (int i = ps * (SROWS / 32); i < (ps + 1) * (SROWS / 32); ++i) {
-          float* const srow = stage + ((i - ps * (SROWS / 32)) * 32 + li) * SROW + wm * WTM + 4 * lh;
+        for (int i = 0; i < TN; ++i) {
+          const int cg = wn * TN + i;  // this wave's 32-channel group inside the tile
+          if (cg >= ps * (SROWS / 32) && cg < (ps + 1) * (SROWS / 32)) {
+            float* const srow = stage + ((cg - ps * (SROWS / 32)) * 32 + li) * SROW + wm * WTM + 4 * lh;
 #pragma unroll
-          for (int j = 0; j < TM; ++j) {
+            for (int j = 0; j < TM; ++j) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              float v[4];
+              for (int q = 0; q < 4; ++q) {
+                float v[4];
+                if constexpr (FLIP) {  // both sets as they are (+ their bias parts): s_out and the constants meet them in the read-out
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(__fmul_rn(__fadd_rn(acc[i][j][4 * q + e], bsv[i]), scv[i]), shv[i]);
-              *reinterpret_cast<float4*>(srow + j * 32 + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+                  for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(acc[0][i][j][4 * q + e], bsv[i]);
+                  *reinterpret_cast<float4*>(srow + j * 32 + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(acc[NOP - 1][i][j][4 * q + e], b1v[i]);
+                  *reinterpret_cast<float4*>(srow + SROWS * SROW + j * 32 + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(__fmul_rn(__fadd_rn(acc[0][i][j][4 * q + e], bsv[i]), scv[i]), shv[i]);
+                  *reinterpret_cast<float4*>(srow + j * 32 + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+              }
             }
           }
         }
@@ -710,12 +795,13 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       }
     } else {
       // Scalar stores: lanes run along the channels (consecutive addresses when Ho*Wo == 1: Linear and 1x1 maps).
-      float bsv[TN], scv[TN], shv[TN];
+      float bsv[TN], scv[TN], shv[TN], b1v[TN];
       bool cok[TN];
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
-        const int co_l = i * 32 + li;
+        const int co_l = (wn * TN + i) * 32 + li;
         bsv[i] = bias0[co_l], scv[i] = osc[co_l], shv[i] = osh[co_l];
+        b1v[i] = FLIP ? bias1[co_l] : 0.f;
         cok[i] = n0 + co_l < a.Cog;
       }
       const int HoWo = a.Ho * a.Wo;
@@ -730,8 +816,10 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
 #pragma unroll
           for (int i = 0; i < TN; ++i) {
             if (live && cok[i]) {
-              const uint32_t oi = base + (uint32_t)((i * 32 + li) * HoWo);
-              float v = __fadd_rn(__fmul_rn(__fadd_rn(acc[i][j][r], bsv[i]), scv[i]), shv[i]);
+              const uint32_t oi = base + (uint32_t)(((wn * TN + i) * 32 + li) * HoWo);
+              float v = __fadd_rn(acc[0][i][j][r], bsv[i]);
+              if constexpr (FLIP) v = __fadd_rn(v, __fmul_rn(__fadd_rn(acc[NOP - 1][i][j][r], b1v[i]), hash_sign(skey_out, oi)));
+              v = __fadd_rn(__fmul_rn(v, scv[i]), shv[i]);
               if (res_s) v = __fadd_rn(v, res_s[oi]);
               v = (relu && v < 0.f) ? 0.f : v;
               out_s[oi] = v;

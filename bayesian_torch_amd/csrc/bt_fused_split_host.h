@@ -1,0 +1,93 @@
+// Host-side helpers shared by the split flavour's translation units (bt_fused_split.hip, bt_fused_split_flip.hip).
+#pragma once
+#include "bt_fused_split.h"
+
+namespace bt {
+
+int contraction_mode();  // bt_fused_split.hip: 0 automatic, 1 fp32 MFMA only, 2 bf16x2 (opt-in)
+
+// Extent of the window of taps that can meet data along one axis (the kernel's own rule: bt_fused_split.h), for the whole
+// output axis or -- pixel-major tiles prune per pixel -- the widest window of any single output position.
+static void tap_window(int K, int D, int S, int P, int In, int Out, bool per_pixel, int* n_act, int* extent, int* n_min = nullptr) {
+  int best_n = 0, best_ext = 0, least_n = 1 << 30;
+  if (per_pixel) {
+    for (int o = 0; o < Out; ++o) {
+      int lo = 1 << 30, hi = -1, n = 0;
+      for (int k = 0; k < K; ++k)
+        if ((unsigned)(o * S - P + k * D) < (unsigned)In) lo = k * D < lo ? k * D : lo, hi = k * D > hi ? k * D : hi, ++n;
+      if (n > best_n) best_n = n;
+      if (n < least_n) least_n = n;
+      if (hi - lo > best_ext) best_ext = hi - lo;
+    }
+    if (n_min) *n_min = least_n;
+  } else {
+    int lo = 1 << 30, hi = -1;
+    for (int k = 0; k < K; ++k) {
+      const int l = P - k * D, c = l > 0 ? (l + S - 1) / S : 0;
+      if (c < Out && c * S - l < In) lo = k * D < lo ? k * D : lo, hi = k * D > hi ? k * D : hi, ++best_n;
+    }
+    best_ext = hi >= lo ? hi - lo : 0;
+  }
+  *n_act = best_n, *extent = best_ext;
+}
+
+// Stride-1 tiles of whole output rows: does the patch (window of the active taps) cover every column of the input rows? Then
+// the halo of the patch is zero padding only and the x fetch can move whole 16-byte row pieces (XM 3).
+static bool split_rows_cover(const FwdArgs& a) {
+  int lo = 1 << 30, hi = -1;
+  for (int k = 0; k < a.KW; ++k) {
+    const int l = a.PW - k * a.DW, c = l > 0 ? l : 0;  // stride 1
+    if (c < a.Wo && c - l < a.W) lo = k * a.DW < lo ? k * a.DW : lo, hi = k * a.DW > hi ? k * a.DW : hi;
+  }
+  if (hi < 0) return false;
+  const int x_lo = -a.PW + lo, x_hi = (a.Wo - 1) - a.PW + hi;  // first / last input column of the patch
+  return x_lo <= 0 && x_hi >= a.W - 1;
+}
+
+// Tile geometry as bt_fused_dispatch.h's fast_geometry, with the split flavour's capacity: the patch of ONE octet plane has to
+// fit XPO pixels. Fills the tile fields and returns the tile's live columns (0: does not fit).
+template <int BM, bool FLIP = false>
+static int split_geometry(FwdArgs& a) {
+  int nh, nw, dys, dxs, nh_min = 0, nw_min = 0;
+  tap_window(a.KH, a.DH, a.SH, a.PH, a.H, a.Ho, a.pixel_major != 0, &nh, &dys, &nh_min);
+  tap_window(a.KW, a.DW, a.SW, a.PW, a.W, a.Wo, a.pixel_major != 0, &nw, &dxs, &nw_min);
+  // One active tap: the canonical K order pairs consecutive octets in one MFMA step, so a stage has to hold TWO octet planes
+  // whatever the tile (otherwise the pairing, and with it the rounding, would depend on the tile choice). Pixel-major tiles
+  // prune per pixel: the rule applies when some pixel is left with a single tap.
+  const bool one_tap = a.pixel_major ? nh_min * nw_min <= 1 : nh * nw <= 1;
+  const long long XPO = one_tap ? (split_xpo<BM, FLIP>() - 1) / 2 : split_xpo<BM, FLIP>() - 1;   // (one slot is the shared zero pixel)
+  auto fits = [&](int NI, int R, int Wt) {
+    // the patch stores only pixels that exist: at most the window's rows / columns, at most the image's (on the patch grid)
+    long long PHt = (long long)(R - 1) * (dys ? a.SH : 1) + dys + 1, PWt = (long long)(Wt - 1) * (dxs ? a.SW : 1) + dxs + 1;
+    const long long rows_max = dys ? a.H : (a.H - 1) / a.SH + 1, cols_max = dxs ? a.W : (a.W - 1) / a.SW + 1;
+    if (PHt > rows_max) PHt = rows_max;
+    if (PWt > cols_max) PWt = cols_max;
+    return NI * PHt * PWt <= XPO;
+  };
+  int NI, R, Wt;
+  if (a.HoWo == 1 || a.pixel_major) {
+    NI = BM, R = 1, Wt = 1;
+    if (NI > a.B) NI = a.B;
+    if (!fits(NI, R, Wt)) return 0;
+  } else if (a.HoWo <= BM) {
+    NI = BM / a.HoWo, R = a.Ho, Wt = a.Wo;  // whole images
+    if (NI > a.B) NI = a.B;
+    while (NI > 1 && !fits(NI, R, Wt)) --NI;
+    if (!fits(NI, R, Wt)) return 0;
+  } else if (a.Wo <= BM) {
+    NI = 1, R = BM / a.Wo, Wt = a.Wo;  // a band of rows of one image
+    while (R > 1 && !fits(NI, R, Wt)) --R;
+    if (!fits(NI, R, Wt)) return 0;
+  } else {
+    NI = 1, R = 1, Wt = BM;  // a segment of one row
+    if (!fits(NI, R, Wt)) return 0;
+  }
+  a.t_NI = NI, a.t_R = R, a.t_Wt = Wt;
+  a.n_bt = (a.B + NI - 1) / NI;
+  a.n_rt = a.pixel_major ? a.Ho : (a.HoWo > 1 ? (a.Ho + R - 1) / R : 1);
+  a.n_ct = a.pixel_major ? a.Wo : (a.HoWo > 1 ? (a.Wo + Wt - 1) / Wt : 1);
+  a.m_tiles = a.n_bt * a.n_rt * a.n_ct;
+  return NI * R * Wt;
+}
+
+}  // namespace bt
