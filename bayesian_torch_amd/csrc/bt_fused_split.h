@@ -57,6 +57,14 @@ __device__ __forceinline__ uint32_t pack_hi16(uint32_t hi, uint32_t lo) {  // (h
   return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
 }
 
+// n / d with the host's reciprocal (bt_fused_split_host.h: inv == 0 -> divide; d == 1 needs none)
+__device__ __forceinline__ int udiv_inv(int n, int d, uint32_t inv) {
+  return inv ? (int)__umulhi((uint32_t)n, inv) : (d == 1 ? n : n / d);
+}
+// ceil(2^32 / d), d >= 2, through ONE 32-bit division: floor((2^32 - 1) / d) + 1
+__device__ __forceinline__ uint32_t inv32(int d) { return 0xFFFFFFFFu / (uint32_t)d + 1u; }
+__device__ __forceinline__ int div_small(int n, int d) { return d == 1 ? n : d == 2 ? n >> 1 : n / d; }  // n >= 0; strides are 1 or 2 in practice
+
 // NP: pieces per value (3: exact split, 6 product terms; 2: 3 terms). 4 consumer waves (64 x BM/4 each) + NPW producer waves
 // (8 on the 128-wide tile of the small feature maps, where one draw serves few columns and the accumulators are small).
 // XM: how the x patch is fetched. A producer thread owns ITEMS f = ptid + kProducers i of the stage's NO octet planes (the same
@@ -73,11 +81,11 @@ __device__ __forceinline__ uint32_t pack_hi16(uint32_t hi, uint32_t lo) {  // (h
 // every x pixel, the sign masks of its 8 channels (bit 15 of each bf16 lane; same hash stream as the fp32 kernels); a consumer
 // issues the 6 terms of x*mu, flips the sign bits of its x fragments in registers (-(h+m+l) = -h-m-l: the split of -v is the
 // negated split of v), and issues the 6 terms of (x o s_in)*(sigma*eps) into the second accumulator set. 4 consumer waves of
-// 32 channels x 128 pixels each (2 x 2), BM = 256. s_out meets the second set in the read-out.
+// 32 channels x BM/2 pixels each (2 x 2), BM = 256 or 128. s_out meets the second set in the read-out.
 template <int BN, int BM, int NP, int NPW, int XM, bool FLIP = false>
 __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdArgs a) {
   static_assert(BN == 64 && (BM == 512 || BM == 256 || BM == 128), "tile shapes of this flavour");
-  static_assert(!FLIP || (BM == 256 && NP == 3 && (XM == 0 || XM == 3)), "Flipout: the 64 x 256 tile, exact split");
+  static_assert(!FLIP || ((BM == 256 || BM == 128) && NP == 3), "Flipout: the 64 x 256 / 64 x 128 tiles, exact split");
   constexpr int kProducers = 64 * NPW, kThreadsAll = 256 + kProducers;
   constexpr int CWM = FLIP ? 2 : 4, CWN = 4 / CWM, WTM = BM / CWM, TN = BN / CWN / 32, TM = WTM / 32;
   constexpr int NOP = FLIP ? 2 : 1;            // weight operands (images per stage) = accumulator sets
@@ -99,26 +107,36 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
 
   unsigned long long* const dbg_ = kStamps ? a.dbg : nullptr;  // stage stamps: diagnostic build only (make STAMPS=1)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (dbg_ && dbg_[201] && tid == 0) {  // diagnostic build: per-workgroup timeline (100 MHz wall clock, shader clock, HW_ID)
+    dbg_[256 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    dbg_[256 + 4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    dbg_[256 + 4 * blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                                     ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);  // HW_ID, XCC_ID
+  }
+  const bool stamp0 = dbg_ && blockIdx.x == 0 && (tid == 0 || tid == 256);
+  if (stamp0 && tid == 0) dbg_[210] = __builtin_amdgcn_s_memtime();
   const bool producer = wave >= 4;
   const int ptid = producer ? tid - 256 : tid;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave & (CWM - 1), wn = (wave & 3) / CWM;  // consumer wave: column block, row block
 
-  int L = xcd_remap(blockIdx.x, a.total_blocks);
-  const int mt = __builtin_amdgcn_readfirstlane(L % a.m_tiles);
-  L /= a.m_tiles;
-  const int s = __builtin_amdgcn_readfirstlane(L % a.S);
-  L /= a.S;
-  const int nt = __builtin_amdgcn_readfirstlane(L % a.n_tiles);
-  const int g = __builtin_amdgcn_readfirstlane(L / a.n_tiles);
+  int L = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, a.total_blocks));
+  int Lq = udiv_inv(L, a.m_tiles, a.inv_m_tiles);
+  const int mt = __builtin_amdgcn_readfirstlane(L - Lq * a.m_tiles);
+  L = Lq, Lq = udiv_inv(L, a.S, a.inv_S);
+  const int s = __builtin_amdgcn_readfirstlane(L - Lq * a.S);
+  L = Lq, Lq = udiv_inv(L, a.n_tiles, a.inv_n_tiles);
+  const int nt = __builtin_amdgcn_readfirstlane(L - Lq * a.n_tiles);
+  const int g = __builtin_amdgcn_readfirstlane(Lq);
   const int n0 = nt * BN;
   const bool pix = a.pixel_major != 0;
   const int t_NI = a.t_NI, t_R = a.t_R, t_Wt = a.t_Wt, RW = t_R * t_Wt, Mt = t_NI * RW;
-  const int bt = __builtin_amdgcn_readfirstlane(mt % a.n_bt), trest = mt / a.n_bt;
-  const int ct = __builtin_amdgcn_readfirstlane(trest % a.n_ct), rt = __builtin_amdgcn_readfirstlane(trest / a.n_ct);
+  const int trest = udiv_inv(mt, a.n_bt, a.inv_n_bt);
+  const int bt = __builtin_amdgcn_readfirstlane(mt - trest * a.n_bt);
+  const int rt = __builtin_amdgcn_readfirstlane(udiv_inv(trest, a.n_ct, a.inv_n_ct)), ct = __builtin_amdgcn_readfirstlane(trest - rt * a.n_ct);
   const int b0 = bt * t_NI, r0 = rt * t_R, w0 = ct * t_Wt;
-  const uint32_t inv_rw = RW > 1 ? (uint32_t)((0x100000000ull + (unsigned)RW - 1) / (unsigned)RW) : 0u;
-  const uint32_t inv_wt = t_Wt > 1 ? (uint32_t)((0x100000000ull + (unsigned)t_Wt - 1) / (unsigned)t_Wt) : 0u;
+  const uint32_t inv_rw = RW > 1 ? (a.inv_rw ? a.inv_rw : inv32(RW)) : 0u;
+  const uint32_t inv_wt = t_Wt > 1 ? (a.inv_wt ? a.inv_wt : inv32(t_Wt)) : 0u;
   auto col_decode = [&](int ml, int& b, int& ho, int& wo) -> bool {  // tile column -> output coordinates; false: dead column
     const int img = RW == 1 ? ml : (int)__umulhi((uint32_t)ml, inv_rw);
     const int rem = ml - img * RW;
@@ -143,18 +161,20 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     skey_out = sign_stream_key(ks, sample);
   }
 
-  // ---- active taps of this tile + their window (wave 0), as in the fast kernel -----------------------------------------
-  if (wave == 0) {
+  // ---- active taps of this tile + their window. Every wave computes them (identical values: the table in LDS is written by
+  // all waves alike, and a wave reads it behind its own writes), so no workgroup barrier opens the kernel. -------------------
+  int nA, dymin, dymax, dxmin, dxmax;
+  {
     bool act = false;
     int4 e = make_int4(0, 0, 0, 0);
     if (lane < T) {
-      const int kh = lane / a.KW, kw = lane - kh * a.KW;
+      const int kh = udiv_inv(lane, a.KW, a.inv_kw), kw = lane - kh * a.KW;
       e = make_int4(0, kh * a.DH, kw * a.DW, lane);
       if (pix) {
         act = (unsigned)(r0 * a.SH - a.PH + e.y) < (unsigned)a.H && (unsigned)(w0 * a.SW - a.PW + e.z) < (unsigned)a.W;
       } else {
         const int lo_h = a.PH - e.y, lo_w = a.PW - e.z;
-        const int hc = lo_h > 0 ? (lo_h + a.SH - 1) / a.SH : 0, wc = lo_w > 0 ? (lo_w + a.SW - 1) / a.SW : 0;
+        const int hc = lo_h > 0 ? div_small(lo_h + a.SH - 1, a.SH) : 0, wc = lo_w > 0 ? div_small(lo_w + a.SW - 1, a.SW) : 0;
         act = hc < a.Ho && hc * a.SH - lo_h < a.H && wc < a.Wo && wc * a.SW - lo_w < a.W;
       }
     }
@@ -166,24 +186,23 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       dy0 = min(dy0, __shfl_xor(dy0, o, 64)), dy1 = max(dy1, __shfl_xor(dy1, o, 64));
       dx0 = min(dx0, __shfl_xor(dx0, o, 64)), dx1 = max(dx1, __shfl_xor(dx1, o, 64));
     }
-    if (lane == 0) misc[0] = __popcll(mask), misc[2] = dy0, misc[3] = dy1, misc[4] = dx0, misc[5] = dx1;
+    nA = __builtin_amdgcn_readfirstlane((int)__popcll(mask));  // 0: degenerate geometry, outputs are the bias alone
+    dymin = __builtin_amdgcn_readfirstlane(dy0), dymax = __builtin_amdgcn_readfirstlane(dy1);
+    dxmin = __builtin_amdgcn_readfirstlane(dx0), dxmax = __builtin_amdgcn_readfirstlane(dx1);
   }
-  __syncthreads();
-  const int nA = __builtin_amdgcn_readfirstlane(misc[0]);  // 0: degenerate geometry, outputs are the bias alone
+  if (stamp0 && tid == 0) dbg_[211] = __builtin_amdgcn_s_memtime();
 
   // ---- stage shape ------------------------------------------------------------------------------------------------------
   // nA > 1: SPO = ceil(nA/2) steps per octet, NO octets per stage. nA == 1: one step per PAIR of octets.
   const int G8 = Cig >> 3;  // host: Cig % 8 == 0
-  const int dymin = __builtin_amdgcn_readfirstlane(misc[2]), dymax = __builtin_amdgcn_readfirstlane(misc[3]);
-  const int dxmin = __builtin_amdgcn_readfirstlane(misc[4]), dxmax = __builtin_amdgcn_readfirstlane(misc[5]);
   const int ps_h = (dymax == dymin) ? 1 : a.SH, gs_h = (dymax == dymin) ? a.SH : 1;
   const int ps_w = (dxmax == dxmin) ? 1 : a.SW, gs_w = (dxmax == dxmin) ? a.SW : 1;
   const int PHt = (t_R - 1) * ps_h + (dymax - dymin) + 1, PWt = (t_Wt - 1) * ps_w + (dxmax - dxmin) + 1;
   const int x_lo = w0 * a.SW - a.PW + dxmin, y_lo = r0 * a.SH - a.PH + dymin;
   // Only the patch rows / columns that exist in the image are stored: grid rows k (input row y_lo + k * gs_h) with
   // kmin_h <= k <= kmax_h, likewise columns. (PHt x PWt is the full window, halo included.)
-  const int kmin_h = y_lo < 0 ? (-y_lo + gs_h - 1) / gs_h : 0, kmin_w = x_lo < 0 ? (-x_lo + gs_w - 1) / gs_w : 0;
-  int kmax_h = a.H - 1 - y_lo >= 0 ? (a.H - 1 - y_lo) / gs_h : -1, kmax_w = a.W - 1 - x_lo >= 0 ? (a.W - 1 - x_lo) / gs_w : -1;
+  const int kmin_h = y_lo < 0 ? div_small(-y_lo + gs_h - 1, gs_h) : 0, kmin_w = x_lo < 0 ? div_small(-x_lo + gs_w - 1, gs_w) : 0;
+  int kmax_h = a.H - 1 - y_lo >= 0 ? div_small(a.H - 1 - y_lo, gs_h) : -1, kmax_w = a.W - 1 - x_lo >= 0 ? div_small(a.W - 1 - x_lo, gs_w) : -1;
   kmax_h = kmax_h < PHt - 1 ? kmax_h : PHt - 1, kmax_w = kmax_w < PWt - 1 ? kmax_w : PWt - 1;
   const int NYR = kmax_h >= kmin_h ? kmax_h - kmin_h + 1 : 0, NXR = kmax_w >= kmin_w ? kmax_w - kmin_w + 1 : 0;
   const int PIMG = NYR * NXR, PCH = t_NI * PIMG;  // real patch pixels of one image / of one octet plane (host: NO * PCH < XPO)
@@ -193,7 +212,8 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
   if (nA <= 1) {
     NO = 2 * kSplitSteps;
   } else {
-    NO = kSplitSteps / SPO;
+    NO = SPO == 1 ? 5 : SPO == 2 ? 2 : 1;  // floor(kSplitSteps / SPO), SPO <= 5 (host: at most 9 taps)
+    static_assert(kSplitSteps == 5, "the table above");
   }
   while (NO > 1 && NO * PCH > XPO - 1) --NO;
   if (nA <= 1 && NO > 1) NO &= ~1;  // whole pairs per stage
@@ -201,9 +221,13 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
   const int NQ = NO * (nA > 0 ? nA : 1);                       // (octet, tap) entries of a full stage
   const int NSTEP = nA <= 1 ? (NO + 1) >> 1 : NO * SPO;        // MFMA steps of a full stage
   const int NS = nA ? (G8 + NO - 1) / NO : 0;
-  // The W slots no unit ever writes (second half of an odd tap count's last step) must hold zeros, and an x entry that is
-  // multiplied by such zeros (or by the zero weights of octets past the end) must at least be finite: clear everything once.
-  for (int i = tid; i < 2 * (W_BYTES + X_BYTES) / 16; i += kThreadsAll) reinterpret_cast<uint4*>(smem_c)[i] = make_uint4(0, 0, 0, 0);
+  // The W slots no unit ever writes (second half of an odd tap count's last step) must hold zeros: clear the W buffers once.
+  // Every x slot a consumer reads is either a real patch pixel of an octet plane of the stage -- written in every stage, with
+  // zeros past the end of the batch / of the channels -- or the shared zero pixel (padding taps, dead columns, the missing
+  // half of an odd last pair): clear the two zero pixels. (The barrier that publishes the clear sits in both arms below,
+  // behind the work that needs no LDS: the producers have issued stage 0's loads by then.)
+  for (int i = tid; i < 2 * W_BYTES / 16; i += kThreadsAll) reinterpret_cast<uint4*>(smem_c)[i] = make_uint4(0, 0, 0, 0);
+  if (tid < 2 * (PB / 16)) reinterpret_cast<uint4*>(xbuf + (tid / (PB / 16)) * X_BYTES + X_BYTES - PB)[tid % (PB / 16)] = make_uint4(0, 0, 0, 0);
 
   const float* const xs = a.x + (long long)s * a.x_sample_stride;
   constexpr uint32_t kOOB = 0x80000000u;
@@ -223,7 +247,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
   float* const out_s = a.out + (long long)s * a.out_elems;
   const float* const res_s = a.ep_res ? a.ep_res + (long long)s * a.ep_res_stride : nullptr;
   const bool relu = a.ep_relu != 0;
-  __syncthreads();  // cleared buffers
+  if (stamp0 && tid == 0) dbg_[212] = __builtin_amdgcn_s_memtime();
 
   // Read-out of one staged pass of the output tile (SROWS channels) by every wave (see the output stage below).
   auto readout_quads = [&](int pass, int t0) {
@@ -280,14 +304,14 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     uint32_t e_off[UMAX];  // draw index (== element offset in the packed tensors) of the unit at octet 0 of stage 0
     int l_off[UMAX];       // LDS byte offset inside a W buffer; -1: no slot
     int u_ol[UMAX];        // octet inside the stage
-    const uint32_t inv_na = nA > 1 ? (uint32_t)((0x100000000ull + (unsigned)nA - 1) / (unsigned)nA) : 0u;
+    const uint32_t inv_na = nA > 1 ? inv32(nA) : 0u;
 #pragma unroll
     for (int i = 0; i < UMAX; ++i) {
       const int u = ptid + kProducers * i;
       const int uu = u < nunits ? u : 0;
       int cq = uu & 1, n = (uu >> 1) & (BN - 1), q = (uu >> 1) / BN;
       if (nA == 1 && NO > 1) {  // one tap: a row's octets are contiguous in the packed tensors -> (quad, octet) fastest
-        const uint32_t inv_no = (uint32_t)((0x100000000ull + (unsigned)NO - 1) / (unsigned)NO);
+        const uint32_t inv_no = inv32(NO);
         const int t2 = uu >> 1;
         n = (int)__umulhi((uint32_t)t2, inv_no);
         q = t2 - n * NO;
@@ -306,6 +330,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       u_ol[i] = ol;
     }
     const int wave_u0 = __builtin_amdgcn_readfirstlane(ptid & ~63);
+    if (stamp0) dbg_[213] = __builtin_amdgcn_s_memtime();
     // x items of this thread (see XM above): global byte offset of the item at octet 0, LDS byte offset inside an x buffer,
     // octet inside the stage.
     constexpr int PIT = XM == 3 ? ((XPO - 1) / 2 + kProducers - 1) / kProducers : (XPO - 1 + kProducers - 1) / kProducers;   // (XPO - 1 patch slots + the zero pixel)
@@ -316,12 +341,12 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     const int per_oct = XM == 2 ? 4 * t_NI : XM == 3 ? 2 * t_NI * nyr * W4 : PCH;   // XM 2: (image, channel pair) items
     const int n_items = NO * per_oct;
     {
-      const uint32_t inv_per = per_oct > 1 ? (uint32_t)((0x100000000ull + (unsigned)per_oct - 1) / (unsigned)per_oct) : 0u;
-      const uint32_t inv_pimg = PIMG > 0 ? (uint32_t)((0x100000000ull + (unsigned)PIMG - 1) / (unsigned)PIMG) : 0u;
-      const uint32_t inv_pw = NXR > 0 ? (uint32_t)((0x100000000ull + (unsigned)NXR - 1) / (unsigned)NXR) : 0u;
+      const uint32_t inv_per = per_oct > 1 ? inv32(per_oct) : 0u;
+      const uint32_t inv_pimg = PIMG > 0 ? inv32(PIMG) : 0u;
+      const uint32_t inv_pw = NXR > 0 ? inv32(NXR) : 0u;
       const int qpi = nyr * W4;  // quads per image (XM 3)
-      const uint32_t inv_qpi = qpi > 1 ? (uint32_t)((0x100000000ull + (unsigned)qpi - 1) / (unsigned)qpi) : 0u;
-      const uint32_t inv_w4 = W4 > 1 ? (uint32_t)((0x100000000ull + (unsigned)W4 - 1) / (unsigned)W4) : 0u;
+      const uint32_t inv_qpi = qpi > 1 ? inv32(qpi) : 0u;
+      const uint32_t inv_w4 = W4 > 1 ? inv32(W4) : 0u;
 #pragma unroll
       for (int i = 0; i < PIT; ++i) {
         const int f = ptid + kProducers * i;
@@ -329,14 +354,14 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         int ol = per_oct <= 1 ? ff : (int)__umulhi((uint32_t)ff, inv_per);
         int r = ff - ol * per_oct;
         if constexpr (XM == 1) {  // octet fastest: consecutive lanes read consecutive 32-byte pieces of one image
-          const uint32_t inv_no = NO > 1 ? (uint32_t)((0x100000000ull + (unsigned)NO - 1) / (unsigned)NO) : 0u;
+          const uint32_t inv_no = NO > 1 ? inv32(NO) : 0u;
           r = NO <= 1 ? ff : (int)__umulhi((uint32_t)ff, inv_no);
           ol = ff - r * NO;
         }
         int pair = 0;
         if constexpr (XM == 2) {  // channel pair fastest, then octet, then image: r = image
           const int cps = 4 * NO;   // channel pairs of a stage
-          const uint32_t inv_cps = (uint32_t)((0x100000000ull + (unsigned)cps - 1) / (unsigned)cps);
+          const uint32_t inv_cps = inv32(cps);
           r = (int)__umulhi((uint32_t)ff, inv_cps);
           const int cp = ff - r * cps;
           ol = cp >> 2, pair = cp & 3;
@@ -373,6 +398,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         it_ol[i] = ol;
       }
     }
+    if (stamp0) dbg_[214] = __builtin_amdgcn_s_memtime();
     const int HWb = 4 * a.HW;
     const int wave_i0 = wave_u0;  // first item index of this wave (iteration 0)
     const int n_items_w = n_items;
@@ -455,6 +481,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
               *reinterpret_cast<uint32_t*>(dst + px * PB) = pack_hi16(h1, h0);
               *reinterpret_cast<uint32_t*>(dst + px * PB + 16) = pack_hi16(m1, m0_);
               if constexpr (NP == 3) *reinterpret_cast<uint32_t*>(dst + px * PB + 32) = pack_hi16(l1, l0);
+              if constexpr (FLIP) *reinterpret_cast<uint32_t*>(dst + px * PB + 16 * NP) = pack_hi16(sign_bit(e0 + 4u + (uint32_t)px), sign_bit(e0 + (uint32_t)px));
             }
           } else if constexpr (XM == 3) {  // 4 pixels x 4 channels: half of each pixel's 16-byte slots
 #pragma unroll
@@ -480,6 +507,8 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       }
     };
     if (NS > 0) load_w(0), load_x(0);
+    if (stamp0) dbg_[215] = __builtin_amdgcn_s_memtime();
+    __syncthreads();  // cleared buffers
     const bool pstamp = dbg_ && blockIdx.x == 0 && tid == 256;
     for (int st = 0; st <= NS; ++st) {  // NS + 1 barriers, like the consumer arm
       if (pstamp && st < 60) dbg_[128 + 2 * st] = __builtin_amdgcn_s_memtime();
@@ -640,7 +669,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       for (int q = 0; q < kSplitSteps; ++q) {
         int ol, ai;  // entry of (step q, this lane half)
         if (nA <= 1) ol = 2 * q + lh, ai = 0;
-        else ol = q / SPO, ai = 2 * (q - ol * SPO) + lh;
+        else ol = (q >= SPO) + (q >= 2 * SPO) + (q >= 3 * SPO) + (q >= 4 * SPO), ai = 2 * (q - ol * SPO) + lh;  // q / SPO, q < 5
         const bool ent = nA > 0 && ol < NO && ai < nA;
         const int4 e = taptab[ent ? ai : 0];
         const int ty = (dymax == dymin) ? 0 : e.y - dymin, tx = (dxmax == dxmin) ? 0 : e.z - dxmin;
@@ -668,6 +697,8 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     if (prio_mode == 2) __builtin_amdgcn_s_setprio(3);
 
     const bool cstamp = dbg_ && blockIdx.x == 0 && tid == 0;
+    if (cstamp) dbg_[216] = __builtin_amdgcn_s_memtime();
+    __syncthreads();  // cleared buffers
     __syncthreads();  // stage 0 staged
     if (cstamp) dbg_[0] = __builtin_amdgcn_s_memtime();
     for (int st = 0; st < NS; ++st) {
@@ -830,6 +861,10 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     }
   }
   if (dbg_ && blockIdx.x == 0 && tid == 0) dbg_[126] = __builtin_amdgcn_s_memtime();
+  if (dbg_ && dbg_[201] && tid == 0) {
+    dbg_[256 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    dbg_[256 + 4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime() - dbg_[256 + 4 * blockIdx.x + 2];
+  }
 }
 
 }  // namespace bt

@@ -37,6 +37,7 @@ static int launch_split_cfg(FwdArgs& a, hipStream_t stream) {
   char nm[160];
   snprintf(nm, sizeof(nm), "fused_split_kernel<%d,%d,bf16x%d,%d terms,npw=%d,xm=%d>", BN, BM, NP, NP == 3 ? 6 : 3, NPW, XM);
   note_kernel(nm);
+  split_fill_inverses(a);
   hipLaunchKernelGGL(kern, dim3((unsigned)a.total_blocks), dim3(256 + 64 * NPW), lds, stream, a);
   return check_launch("fused forward (split)");
 }

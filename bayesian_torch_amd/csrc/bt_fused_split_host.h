@@ -6,6 +6,25 @@ namespace bt {
 
 int contraction_mode();  // bt_fused_split.hip: 0 automatic, 1 fp32 MFMA only, 2 bf16x2 (opt-in)
 
+// ceil(2^32 / d): __umulhi(n, .) == n / d for every dividend n with n * d < 2^32. 0 when that cannot be promised (or d == 1):
+// the kernel then divides.
+static inline uint32_t inv_u32(long long d, long long nmax) {
+  if (d <= 1 || nmax < 0 || (unsigned long long)nmax * (unsigned long long)d >= (1ull << 32)) return 0u;
+  return (uint32_t)(((1ull << 32) + (unsigned long long)d - 1ull) / (unsigned long long)d);
+}
+// Reciprocals of the launch-uniform divisors of the tile decode (every workgroup used to spend ~2,000 cycles dividing).
+static inline void split_fill_inverses(FwdArgs& a) {
+  const long long tb = a.total_blocks;
+  a.inv_m_tiles = inv_u32(a.m_tiles, tb);
+  a.inv_S = inv_u32(a.S, tb);
+  a.inv_n_tiles = inv_u32(a.n_tiles, tb);
+  a.inv_n_bt = inv_u32(a.n_bt, a.m_tiles);
+  a.inv_n_ct = inv_u32(a.n_ct, a.m_tiles);
+  a.inv_rw = inv_u32((long long)a.t_R * a.t_Wt, 1024);
+  a.inv_wt = inv_u32(a.t_Wt, 1024);
+  a.inv_kw = inv_u32(a.KW, 64);
+}
+
 // Extent of the window of taps that can meet data along one axis (the kernel's own rule: bt_fused_split.h), for the whole
 // output axis or -- pixel-major tiles prune per pixel -- the widest window of any single output position.
 static void tap_window(int K, int D, int S, int P, int In, int Out, bool per_pixel, int* n_act, int* extent, int* n_min = nullptr) {
