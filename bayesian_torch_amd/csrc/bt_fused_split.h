@@ -249,27 +249,37 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
   const bool relu = a.ep_relu != 0;
   if (stamp0 && tid == 0) dbg_[212] = __builtin_amdgcn_s_memtime();
 
-  // Read-out of one staged pass of the output tile (SROWS channels) by every wave (see the output stage below).
+  // Read-out of one staged pass of the output tile (SROWS channels) by every wave (see the output stage below). A thread's
+  // items share one pixel quad (the thread count is a multiple of the quads per row) and step RSTEP channels: the quad is
+  // decoded once, an item costs an add (this loop is bound by the VALU issue of its index arithmetic, not by the stores).
   auto readout_quads = [&](int pass, int t0) {
-    constexpr int SROW = BM + 4, QROW = BM / 4, NQD = SROWS * QROW, NT_ = kThreadsAll;
-    constexpr int NITc = (NQD + NT_ - 1) / NT_, U = NITc < 8 ? NITc : 8;
+    constexpr int SROW = BM + 4, QROW = BM / 4, NT_ = kThreadsAll;
+    static_assert(NT_ % QROW == 0, "a thread keeps its pixel quad");
+    constexpr int RSTEP = NT_ / QROW, NITc = (SROWS + RSTEP - 1) / RSTEP, U = NITc < 8 ? NITc : 8;
     const float* const stage = smem + 4 * BN;
-    for (int c0q = t0; c0q < NQD; c0q += NT_ * U) {
+    const int m4 = t0 % QROW, row0 = t0 / QROW;
+    int bq, hq, wq;
+    const bool mok = col_decode(4 * m4, bq, hq, wq);
+    const int HoWo_ = a.Ho * a.Wo;
+    const int co0 = pass * SROWS + row0;  // first channel (inside the tile) of this thread
+    const uint32_t obase = mok ? (uint32_t)(((bq * a.Co + g * a.Cog + n0 + co0) * a.Ho + hq) * a.Wo + wq) : 0u;
+    const int rows_ok = a.Cog - n0 - pass * SROWS < SROWS ? a.Cog - n0 - pass * SROWS : SROWS;  // staged rows that are channels
+    const float* const sp = stage + row0 * SROW + 4 * m4;
+#pragma unroll
+    for (int k0 = 0; k0 < NITc; k0 += U) {
       uint32_t oidx[U];
       bool okq[U];
       float4 v[U], r4[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int cr = c0q + NT_ * u, c = cr < NQD ? cr : 0;
-        const int row = c / QROW, m4 = c - row * QROW;
-        int bq, hq, wq;
-        const bool mok = col_decode(4 * m4, bq, hq, wq);
-        const int co_l = pass * SROWS + row;
-        okq[u] = cr < NQD && mok && n0 + co_l < a.Cog;
-        oidx[u] = okq[u] ? (uint32_t)(((bq * a.Co + g * a.Cog + n0 + co_l) * a.Ho + hq) * a.Wo + wq) : 0u;
-        v[u] = *reinterpret_cast<const float4*>(stage + row * SROW + 4 * m4);
+        const int k = k0 + u, row = row0 + k * RSTEP;
+        okq[u] = k < NITc && mok && row < rows_ok;
+        oidx[u] = okq[u] ? obase + (uint32_t)(k * RSTEP * HoWo_) : 0u;
+        const int rr = row < SROWS ? k * RSTEP : 0;   // (rows past the staged block: any staged address)
+        v[u] = *reinterpret_cast<const float4*>(sp + rr * SROW);
         if constexpr (FLIP) {  // second accumulator set x s_out, then the output-stage constants (the fp32 kernels' order)
-          const float4 d = *reinterpret_cast<const float4*>(stage + (SROWS + row) * SROW + 4 * m4);
+          const float4 d = *reinterpret_cast<const float4*>(sp + (SROWS + rr) * SROW);
+          const int co_l = okq[u] ? co0 + k * RSTEP : 0;
           const float sc = osc[co_l], sh = osh[co_l];
           v[u].x = __fadd_rn(__fmul_rn(__fadd_rn(v[u].x, __fmul_rn(d.x, hash_sign(skey_out, oidx[u]))), sc), sh);
           v[u].y = __fadd_rn(__fmul_rn(__fadd_rn(v[u].y, __fmul_rn(d.y, hash_sign(skey_out, oidx[u] + 1u))), sc), sh);
@@ -331,6 +341,19 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     }
     const int wave_u0 = __builtin_amdgcn_readfirstlane(ptid & ~63);
     if (stamp0) dbg_[213] = __builtin_amdgcn_s_memtime();
+    float4 mu[UMAX], rs[UMAX];
+    auto load_w = [&](int st) {
+      const int oct0 = st * NO;
+#pragma unroll
+      for (int i = 0; i < UMAX; ++i) {
+        if (i == 0 || wave_u0 + kProducers * i < nunits) {  // wave-uniform
+          const bool in = l_off[i] >= 0 && oct0 + u_ol[i] < G8 && e_off[i] != (kOOB >> 2);
+          const uint32_t sb = in ? 4u * (e_off[i] + (uint32_t)(8 * oct0)) : kOOB;
+          mu[i] = ldf4(r_mu, sb), rs[i] = ldf4(r_rs, sb);
+        }
+      }
+    };
+    if (NS > 0) load_w(0);  // stage 0's weight loads fly while the x items are decoded
     // x items of this thread (see XM above): global byte offset of the item at octet 0, LDS byte offset inside an x buffer,
     // octet inside the stage.
     constexpr int PIT = XM == 3 ? ((XPO - 1) / 2 + kProducers - 1) / kProducers : (XPO - 1 + kProducers - 1) / kProducers;   // (XPO - 1 patch slots + the zero pixel)
@@ -405,19 +428,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
 
     // One stage = loads (issued one stage AHEAD, into registers that the previous stage has just consumed) -> draws (pure
     // ALU: they run while the loads are in flight) -> sampled weights -> pieces -> LDS -> activations -> pieces -> LDS.
-    float4 mu[UMAX], rs[UMAX];
     float xv[PIT][XV];
-    auto load_w = [&](int st) {
-      const int oct0 = st * NO;
-#pragma unroll
-      for (int i = 0; i < UMAX; ++i) {
-        if (i == 0 || wave_u0 + kProducers * i < nunits) {  // wave-uniform
-          const bool in = l_off[i] >= 0 && oct0 + u_ol[i] < G8 && e_off[i] != (kOOB >> 2);
-          const uint32_t sb = in ? 4u * (e_off[i] + (uint32_t)(8 * oct0)) : kOOB;
-          mu[i] = ldf4(r_mu, sb), rs[i] = ldf4(r_rs, sb);
-        }
-      }
-    };
     auto load_x = [&](int st) {  // every item of stage st
       const int oct0 = st * NO;
 #pragma unroll
@@ -506,7 +517,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         }
       }
     };
-    if (NS > 0) load_w(0), load_x(0);
+    if (NS > 0) load_x(0);
     if (stamp0) dbg_[215] = __builtin_amdgcn_s_memtime();
     __syncthreads();  // cleared buffers
     const bool pstamp = dbg_ && blockIdx.x == 0 && tid == 256;
@@ -779,6 +790,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     if (cstamp) dbg_[1] = __builtin_amdgcn_s_memtime();
     __syncthreads();  // the producers have staged bias / output-stage constants; every consumer wave has published its KL partial
     if (kl_block && wave == 0) kl_ticket();
+    if (cstamp) dbg_[120] = __builtin_amdgcn_s_memtime();
 
     // ---- output stage + store (bt_fused_fast.h: lane = one channel, registers 4q..4q+3 = 4 consecutive positions) ----
     if (a.out_vec4) {
@@ -821,8 +833,11 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
             }
           }
         }
+        if (cstamp) dbg_[121] = __builtin_amdgcn_s_memtime();
         __syncthreads();
+        if (cstamp) dbg_[122] = __builtin_amdgcn_s_memtime();
         readout_quads(ps, tid);
+        if (cstamp) dbg_[123] = __builtin_amdgcn_s_memtime();
       }
     } else {
       // Scalar stores: lanes run along the channels (consecutive addresses when Ho*Wo == 1: Linear and 1x1 maps).
