@@ -31,6 +31,7 @@ struct BwdArgs {
   long long x_sample_stride, x_elems, out_elems, w_elems;
   int B, Ci, H, W, Co, KH, KW, SH, SW, PH, PW, DH, DW, G;
   int Ho, Wo, Cig, Cog, Cig4, T, S, flip, groups;
+  int sgroups, mchunk;              // wgrad: groups = sgroups (sample s handled by s % sgroups) x chunks of mchunk rows of M = B*Ho*Wo
   uint32_t seed_lo, seed_hi, call, layer_id, sample0;
   const uint32_t* call_base;
 };
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(256) void dgrad_kernel(const BwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------ wgrad
-// grid: (k' tiles of 64 over T*Cig4) x (co tiles of 64 per group) x (groups * G); sample sg handled by group sg % groups
+// grid: (k' tiles of 64 over T*Cig4) x (co tiles of 64 per group) x (groups * G); group q = (sample group q % sgroups: samples
+// s = q % sgroups + i * sgroups) x (chunk q / sgroups of the reduction axis M = B*Ho*Wo: rows [c * mchunk, (c + 1) * mchunk))
 template <bool FLIP>
 __global__ __launch_bounds__(256) void wgrad_kernel(const BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float As[FLIP ? 2 : 1][kBK][kLS];   // [mm][co]: g (Flipout: g | g o s_out)
@@ -165,7 +167,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const BwdArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc_mu[r] = 0.f, acc_rho[r] = 0.f;
 
-  for (int s = sgrp; s < a.S; s += a.groups) {
+  const int sg0 = sgrp % a.sgroups, mlo = (sgrp / a.sgroups) * a.mchunk, mhi = mlo + a.mchunk < M ? mlo + a.mchunk : M;
+  for (int s = sg0; s < a.S; s += a.sgroups) {
     const uint32_t sample = a.sample0 + (uint32_t)s;
     uint32_t skey_in = 0, skey_out = 0;
     if (FLIP && !a.sign_in) skey_in = sign_stream_key(bwd_key(a, 2), sample), skey_out = sign_stream_key(bwd_key(a, 3), sample);
@@ -176,12 +179,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const BwdArgs a) {
     for (int w = 0; w < (FLIP ? 2 : 1); ++w)
 #pragma unroll
       for (int r = 0; r < 16; ++r) d[w][r] = 0.f;
-    for (int mm0 = 0; mm0 < M; mm0 += kBK) {
+    for (int mm0 = mlo; mm0 < mhi; mm0 += kBK) {
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int mm = (tid >> 6) + 4 * j, m = mm0 + mm;
-        const bool mok = m < M;
+        const bool mok = m < mhi;
         const int b = mok ? m / HoWo : 0, p = mok ? m - b * HoWo : 0, ho = p / a.Wo, wo = p - ho * a.Wo;
         float ga = 0.f, gp = 0.f, xv = 0.f, xp = 0.f;
         if (mok && cok) {
@@ -286,13 +289,27 @@ __global__ __launch_bounds__(256) void kl_normal_bwd_kernel(const float* __restr
   }
 }
 
-static int wgrad_groups(const bt_conv2d_geom& g, int S) {
+// Workgroups per output tile: first the samples (each group keeps whole samples), then chunks of the reduction axis
+// M = B*Ho*Wo (a training step has ONE sample: layer1's 9 output tiles would otherwise be 9 workgroups on 256 CUs).
+// Chunks are multiples of the LDS stage and at least 8 stages long.
+static int wgrad_groups(const bt_conv2d_geom& g, int S, int* sgroups = nullptr, int* mchunk = nullptr) {
   const int Cig = g.Ci / g.groups, Cog = g.Co / g.groups, Cig4 = (Cig + 3) & ~3, T = g.kh * g.kw;
   const long long tiles = (long long)((T * Cig4 + 63) / 64) * ((Cog + 63) / 64) * g.groups;
   long long gr = (512 + tiles - 1) / tiles;  // aim at two workgroups per CU
-  if (gr > S) gr = S;
   if (gr < 1) gr = 1;
-  return (int)gr;
+  const long long gs = gr > S ? S : gr;
+  const int Ho = (g.H + 2 * g.ph - g.dh * (g.kh - 1) - 1) / g.sh + 1, Wo = (g.W + 2 * g.pw - g.dw * (g.kw - 1) - 1) / g.sw + 1;
+  const long long M = (long long)g.B * Ho * Wo;
+  long long gm = (gr + gs - 1) / gs;
+  const long long max_gm = (M + 8 * kBK - 1) / (8 * kBK);
+  if (gm > max_gm) gm = max_gm;
+  if (gm < 1) gm = 1;
+  long long chunk = (M + gm - 1) / gm;
+  chunk = (chunk + kBK - 1) / kBK * kBK;
+  gm = (M + chunk - 1) / chunk;
+  if (sgroups) *sgroups = (int)gs;
+  if (mchunk) *mchunk = (int)chunk;
+  return (int)(gs * gm);
 }
 
 }  // namespace bt
@@ -339,7 +356,7 @@ extern "C" int bt_conv2d_bwd(const bt_conv2d_geom* g, int32_t S, int32_t flipout
     if (int rc = check_launch("bt_conv2d_bwd (dgrad)")) return rc;
   }
   if (dmu_w) {
-    a.groups = wgrad_groups(*g, S);
+    a.groups = wgrad_groups(*g, S, &a.sgroups, &a.mchunk);
     if (!workspace || workspace_bytes < bt_conv2d_bwd_workspace(g, S)) return set_error(BT_ERR_WORKSPACE, "bt_conv2d_bwd: workspace smaller than bt_conv2d_bwd_workspace()");
     dim3 grid((unsigned)((a.T * a.Cig4 + 63) / 64), (unsigned)((a.Cog + 63) / 64), (unsigned)(a.groups * g->groups));
     if (flipout) hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(256), 0, st, a);
