@@ -31,6 +31,7 @@ struct BwdArgs {
   long long x_sample_stride, x_elems, out_elems, w_elems;
   int B, Ci, H, W, Co, KH, KW, SH, SW, PH, PW, DH, DW, G;
   int Ho, Wo, Cig, Cog, Cig4, T, S, flip, groups;
+  int dchunks, dchunk;              // dgrad: the reduction over output channels in dchunks pieces of dchunk channels (partials in `part`)
   int sgroups, mchunk;              // wgrad: groups = sgroups (sample s handled by s % sgroups) x chunks of mchunk rows of M = B*Ho*Wo
   uint32_t seed_lo, seed_hi, call, layer_id, sample0;
   const uint32_t* call_base;
@@ -48,14 +49,18 @@ __device__ __forceinline__ RngKey bwd_key(const BwdArgs& a, uint32_t tensor) {
 }
 
 // ------------------------------------------------------------------------------------------------------------ dgrad
-// grid: (m tiles of 64 positions of one sample) x (ci tiles of 64 per group) x (S * G)
+// grid: (m tiles of 64 positions of one sample) x (ci tiles of 64 per group) x (S * G * dchunks). Taps that connect no
+// position of the tile to an output are skipped (3x3 on 1x1 maps: 8 of 9). With dchunks > 1 a workgroup reduces over its
+// piece of the output channels and writes a partial; dgrad_finish_kernel adds the pieces in order.
 template <bool FLIP>
 __global__ __launch_bounds__(256) void dgrad_kernel(const BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float As[FLIP ? 2 : 1][kBK][kLS];   // [kk][ci]: W (Flipout: mu | sigma*eps)
   __shared__ __attribute__((aligned(16))) float Bs[FLIP ? 2 : 1][kBK][kLS];   // [kk][col]: g (Flipout: g | g o s_out)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-  const int s = blockIdx.z / a.G, grp = blockIdx.z % a.G;
+  const int kc = blockIdx.z / (a.S * a.G), zr = blockIdx.z - kc * (a.S * a.G);
+  const int s = zr / a.G, grp = zr % a.G;
+  const int co_lo = kc * a.dchunk, co_hi = co_lo + a.dchunk < a.Cog ? co_lo + a.dchunk : a.Cog;
   const int ci0 = blockIdx.y * 64, m0 = blockIdx.x * 64;
   const int HW = a.H * a.W, M = a.B * HW, HoWo = a.Ho * a.Wo;
   const uint32_t sample = a.sample0 + (uint32_t)s;
@@ -83,12 +88,13 @@ __global__ __launch_bounds__(256) void dgrad_kernel(const BwdArgs a) {
     const int ho = nh / a.SH, wo = nw / a.SW;
     const bool pok = mok && nh >= 0 && nw >= 0 && nh - ho * a.SH == 0 && nw - wo * a.SW == 0 && ho < a.Ho && wo < a.Wo;
     const long long gpix = pok ? (long long)mb * a.Co * HoWo + (long long)ho * a.Wo + wo : 0;
-    for (int co0 = 0; co0 < a.Cog; co0 += kBK) {
+    if (!__syncthreads_or(pok ? 1 : 0)) continue;  // this tap meets only padding for every position of the tile
+    for (int co0 = co_lo; co0 < co_hi; co0 += kBK) {
       __syncthreads();
       {  // ---- A: 4 consecutive input channels of (co, tap) = one Philox block of the forward's stream
         const int cog = co0 + akk, co = grp * a.Cog + cog;
         float4 wmu = make_float4(0, 0, 0, 0), wd = make_float4(0, 0, 0, 0);
-        if (cog < a.Cog && aci < a.Cig4) {
+        if (cog < co_hi && aci < a.Cig4) {
           const uint32_t e = ((uint32_t)co * (uint32_t)a.T + (uint32_t)tap) * (uint32_t)a.Cig4 + (uint32_t)aci;
           const float4 m4 = *reinterpret_cast<const float4*>(a.mu_pk + e), s4 = *reinterpret_cast<const float4*>(a.sig_pk + e);
           float ep[4];
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(256) void dgrad_kernel(const BwdArgs a) {
       for (int j = 0; j < 4; ++j) {  // ---- B: upstream gradient at the position this tap connects
         const int kk = (tid >> 6) + 4 * j, cog = co0 + kk;
         float v = 0.f, vp = 0.f;
-        if (pok && cog < a.Cog) {
+        if (pok && cog < co_hi) {
           const long long oi = gpix + (long long)(grp * a.Cog + cog) * HoWo;
           v = gs[oi];
           if (FLIP) vp = __fmul_rn(v, a.sign_out ? a.sign_out[(long long)s * a.out_elems + oi] : hash_sign(skey_out, (uint32_t)oi));
@@ -136,9 +142,20 @@ __global__ __launch_bounds__(256) void dgrad_kernel(const BwdArgs a) {
         const long long xi = ((long long)b * a.Ci + grp * a.Cig + ci) * HW + hw;
         float v = acc[0][r];
         if (FLIP) v = __fadd_rn(v, __fmul_rn(acc[FLIP ? 1 : 0][r], a.sign_in ? a.sign_in[(long long)s * a.x_elems + xi] : hash_sign(skey_in, (uint32_t)xi)));
-        a.dx[(long long)s * a.x_elems + xi] = v;
+        if (a.dchunks > 1) a.part[((long long)kc * a.S + s) * a.x_elems + xi] = v;
+        else a.dx[(long long)s * a.x_elems + xi] = v;
       }
     }
+  }
+}
+
+// dx <- sum of the dchunks partials, in piece order
+__global__ __launch_bounds__(256) void dgrad_finish_kernel(const BwdArgs a) {
+  const long long n = (long long)a.S * a.x_elems;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float v = 0.f;
+    for (int c = 0; c < a.dchunks; ++c) v = __fadd_rn(v, a.part[(long long)c * n + i]);
+    a.dx[i] = v;
   }
 }
 
@@ -312,12 +329,32 @@ static int wgrad_groups(const bt_conv2d_geom& g, int S, int* sgroups = nullptr, 
   return (int)(gs * gm);
 }
 
+// dgrad: pieces of the output-channel reduction, so that a launch offers ~512 workgroups (layer4 of a CIFAR ResNet at one
+// sample: 16 tiles); pieces are multiples of the LDS stage and at least 32 channels.
+static int dgrad_chunks(const bt_conv2d_geom& g, int S, int* dchunk = nullptr) {
+  const int Cig = g.Ci / g.groups, Cog = g.Co / g.groups;
+  const long long M = (long long)g.B * g.H * g.W;
+  const long long tiles = ((M + 63) / 64) * ((Cig + 63) / 64) * S * g.groups;
+  long long c = (512 + tiles - 1) / tiles;
+  const long long max_c = (Cog + 31) / 32;
+  if (c > max_c) c = max_c;
+  if (c < 1) c = 1;
+  long long per = (Cog + c - 1) / c;
+  per = (per + kBK - 1) / kBK * kBK;
+  c = (Cog + per - 1) / per;
+  if (dchunk) *dchunk = (int)per;
+  return (int)c;
+}
+
 }  // namespace bt
 
 extern "C" size_t bt_conv2d_bwd_workspace(const bt_conv2d_geom* g, int32_t S) {
   if (!g || S <= 0 || g->groups <= 0) return 0;
   const int Cig = g->Ci / g->groups, Cig4 = (Cig + 3) & ~3, T = g->kh * g->kw;
-  return (size_t)2 * bt::wgrad_groups(*g, S) * g->Co * T * Cig4 * sizeof(float);
+  const size_t wg = (size_t)2 * bt::wgrad_groups(*g, S) * g->Co * T * Cig4 * sizeof(float);
+  const int dc = bt::dgrad_chunks(*g, S);
+  const size_t dg = dc > 1 ? (size_t)dc * S * g->B * g->Ci * g->H * g->W * sizeof(float) : 0;   // (the two passes run one after the other)
+  return wg > dg ? wg : dg;
 }
 
 extern "C" int bt_conv2d_bwd(const bt_conv2d_geom* g, int32_t S, int32_t flipout, const float* x, int64_t x_sample_stride, const float* grad_out,
@@ -350,10 +387,18 @@ extern "C" int bt_conv2d_bwd(const bt_conv2d_geom* g, int32_t S, int32_t flipout
   hipStream_t st = (hipStream_t)stream;
   if (dx) {
     const long long M = (long long)g->B * g->H * g->W;
-    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((a.Cig + 63) / 64), (unsigned)(S * g->groups));
+    a.dchunks = dgrad_chunks(*g, S, &a.dchunk);
+    if (a.dchunks > 1 && (!workspace || workspace_bytes < bt_conv2d_bwd_workspace(g, S)))
+      return set_error(BT_ERR_WORKSPACE, "bt_conv2d_bwd: workspace smaller than bt_conv2d_bwd_workspace()");
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((a.Cig + 63) / 64), (unsigned)(S * g->groups * a.dchunks));
     if (flipout) hipLaunchKernelGGL(dgrad_kernel<true>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dgrad_kernel<false>, grid, dim3(256), 0, st, a);
     if (int rc = check_launch("bt_conv2d_bwd (dgrad)")) return rc;
+    if (a.dchunks > 1) {
+      const long long n = (long long)S * a.x_elems;
+      hipLaunchKernelGGL(dgrad_finish_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, a);
+      if (int rc = check_launch("bt_conv2d_bwd (dgrad finish)")) return rc;
+    }
   }
   if (dmu_w) {
     a.groups = wgrad_groups(*g, S, &a.sgroups, &a.mchunk);

@@ -189,9 +189,8 @@ def fused_backward(x, grad_out, mu_w, rho_w, packed, *, flip=False, conv=None, S
     dmu = torch.empty_like(mu_w) if need_w else None
     drho = torch.empty_like(mu_w) if need_w else None
     L = _lib.lib()
-    ws = None
-    if need_w:
-        ws = torch.empty(max(16, L.bt_conv2d_bwd_workspace(C.byref(geom), S)), dtype=torch.uint8, device=dev)
+    # partials of wgrad's sample / reduction groups and of dgrad's output-channel pieces (contents need not be initialised)
+    ws = torch.empty(max(16, L.bt_conv2d_bwd_workspace(C.byref(geom), S)), dtype=torch.uint8, device=dev)
     inj = [None if t is None else _lib.dev_f32(t, "draw") for t in (eps_w, sign_in, sign_out)]
     P = _lib.bt_params(mu_w.data_ptr(), rho_w.data_ptr(), None, None, None, None, None, None, packed[0].data_ptr(), packed[1].data_ptr(), 0, 0)
     R = _rng(seed, call, layer_id, sample0, None)

@@ -200,7 +200,8 @@ int bt_rng_philox_raw(uint64_t seed, const uint32_t ctr[4], uint32_t out_host[4]
  *   dx      [S][B][Ci][H][W] or NULL: per-sample input gradient (sum over S yourself when the forward shared x);
  *   dmu_w / drho_w  the parameters' own layout [Co][Ci/groups][kh][kw], both or neither:
  *           dmu = sum_s dW_s,  drho = sigmoid(rho) * sum_s eps_s o dW_s  (Flipout: mean path -> mu, perturbation path -> rho);
- *   workspace: bt_conv2d_bwd_workspace(g, S) bytes (partials of the sample groups; contents need not be initialised).
+ *   workspace: bt_conv2d_bwd_workspace(g, S) bytes (partials of wgrad's sample / reduction groups and of dgrad's pieces of the
+ *           output-channel reduction, summed in a fixed order; contents need not be initialised; needed whenever dx or dmu_w is).
  * Linear layers: g = {B, In, 1, 1, Out, 1, 1, 1, 1, 0, 0, 1, 1, 1}. p needs rho_w, mu_packed, sigma_packed. Bias gradients are
  * row sums of grad_out (not part of this call). */
 size_t bt_conv2d_bwd_workspace(const bt_conv2d_geom *g, int32_t S);
