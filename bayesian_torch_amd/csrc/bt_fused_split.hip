@@ -69,6 +69,7 @@ static int launch_quad_cfg(FwdArgs& a, int mode, hipStream_t stream) {
       flags[mode == 2][dev] = true;
     }
     note_kernel(nm);
+    split_fill_inverses(a);
     hipLaunchKernelGGL(kern, dim3((unsigned)a.total_blocks), dim3(512), lds, stream, a);
     return check_launch("fused forward (split, quad)");
   };

@@ -46,20 +46,22 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave & 3;
 
-  int L = xcd_remap(blockIdx.x, a.total_blocks);
-  const int mt = __builtin_amdgcn_readfirstlane(L % a.m_tiles);
-  L /= a.m_tiles;
-  const int s = __builtin_amdgcn_readfirstlane(L % a.S);
-  L /= a.S;
-  const int nt = __builtin_amdgcn_readfirstlane(L % a.n_tiles);
-  const int g = __builtin_amdgcn_readfirstlane(L / a.n_tiles);
+  int L = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, a.total_blocks));   // (reciprocals from the host: bt_fused_split_host.h)
+  int Lq = udiv_inv(L, a.m_tiles, a.inv_m_tiles);
+  const int mt = __builtin_amdgcn_readfirstlane(L - Lq * a.m_tiles);
+  L = Lq, Lq = udiv_inv(L, a.S, a.inv_S);
+  const int s = __builtin_amdgcn_readfirstlane(L - Lq * a.S);
+  L = Lq, Lq = udiv_inv(L, a.n_tiles, a.inv_n_tiles);
+  const int nt = __builtin_amdgcn_readfirstlane(L - Lq * a.n_tiles);
+  const int g = __builtin_amdgcn_readfirstlane(Lq);
   const int n0 = nt * BN;
   const int t_NI = a.t_NI, t_R = a.t_R, t_Wt = a.t_Wt, RW = t_R * t_Wt, Mt = t_NI * RW;
-  const int bt = __builtin_amdgcn_readfirstlane(mt % a.n_bt), trest = mt / a.n_bt;
-  const int ct = __builtin_amdgcn_readfirstlane(trest % a.n_ct), rt = __builtin_amdgcn_readfirstlane(trest / a.n_ct);
+  const int trest = udiv_inv(mt, a.n_bt, a.inv_n_bt);
+  const int bt = __builtin_amdgcn_readfirstlane(mt - trest * a.n_bt);
+  const int rt = __builtin_amdgcn_readfirstlane(udiv_inv(trest, a.n_ct, a.inv_n_ct)), ct = __builtin_amdgcn_readfirstlane(trest - rt * a.n_ct);
   const int b0 = bt * t_NI, r0 = rt * t_R, w0 = ct * t_Wt;
-  const uint32_t inv_rw = RW > 1 ? (uint32_t)((0x100000000ull + (unsigned)RW - 1) / (unsigned)RW) : 0u;
-  const uint32_t inv_wt = t_Wt > 1 ? (uint32_t)((0x100000000ull + (unsigned)t_Wt - 1) / (unsigned)t_Wt) : 0u;
+  const uint32_t inv_rw = RW > 1 ? (a.inv_rw ? a.inv_rw : inv32(RW)) : 0u;
+  const uint32_t inv_wt = t_Wt > 1 ? (a.inv_wt ? a.inv_wt : inv32(t_Wt)) : 0u;
   auto col_decode = [&](int ml, int& b, int& ho, int& wo) -> bool {
     const int img = RW == 1 ? ml : (int)__umulhi((uint32_t)ml, inv_rw);
     const int rem = ml - img * RW;
@@ -80,10 +82,10 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
     bool act = false;
     int4 e = make_int4(0, 0, 0, 0);
     if (lane < T) {
-      const int kh = lane / a.KW, kw = lane - kh * a.KW;
+      const int kh = udiv_inv(lane, a.KW, a.inv_kw), kw = lane - kh * a.KW;
       e = make_int4(0, kh * a.DH, kw * a.DW, lane);
       const int lo_h = a.PH - e.y, lo_w = a.PW - e.z;
-      const int hc = lo_h > 0 ? (lo_h + a.SH - 1) / a.SH : 0, wc = lo_w > 0 ? (lo_w + a.SW - 1) / a.SW : 0;
+      const int hc = lo_h > 0 ? div_small(lo_h + a.SH - 1, a.SH) : 0, wc = lo_w > 0 ? div_small(lo_w + a.SW - 1, a.SW) : 0;
       act = hc < a.Ho && hc * a.SH - lo_h < a.H && wc < a.Wo && wc * a.SW - lo_w < a.W;
     }
     const unsigned long long mask = __ballot(act);
@@ -110,7 +112,8 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
     const int4 e = taptab[i < nA ? i : 0];
     eofftab[i] = ((e.y - dymin) * PWt + (e.z - dxmin)) * PBQ;
   }
-  for (int i = tid; i < 2 * (W_BYTES + X_BYTES) / 16; i += kThreadsAll) reinterpret_cast<uint4*>(smem_c)[i] = make_uint4(0, 0, 0, 0);
+  // (No LDS clear: every W slot of the steps a stage runs is written by its unit -- masked units write zeros -- and every
+  //  pixel of the patch is, its halo as the zeros of out-of-range loads; dead columns read pixel 0.)
 
   const float* const xs = a.x + (long long)s * a.x_sample_stride;
   constexpr uint32_t kOOB = 0x80000000u;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
   float* const out_s = a.out + (long long)s * a.out_elems;
   const float* const res_s = a.ep_res ? a.ep_res + (long long)s * a.ep_res_stride : nullptr;
   const bool relu = a.ep_relu != 0;
-  __syncthreads();  // tap offsets, cleared buffers
+  __syncthreads();  // tap offsets
 
   // ---- read-out of the staged output tile (all BN channels), by every wave ------------------------------------------------
   auto readout_quads = [&](int t0) {
@@ -202,8 +205,8 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
 // ---- the patch, once, by ALL 8 waves (the consumers have nothing to do before the first stage): a thread owns pixels
 //      tid + 512 i; <= 4 channels per pixel, split on the way to LDS ----
   {
-    const uint32_t inv_pimg = (uint32_t)((0x100000000ull + (unsigned)PIMG - 1) / (unsigned)PIMG);
-    const uint32_t inv_pw = (uint32_t)((0x100000000ull + (unsigned)PWt - 1) / (unsigned)PWt);
+    const uint32_t inv_pimg = PIMG > 1 ? inv32(PIMG) : 0u;
+    const uint32_t inv_pw = PWt > 1 ? inv32(PWt) : 0u;
     const int HWb = 4 * a.HW;
     constexpr int XB = 4;  // pixels in flight per thread
     for (int i0 = 0; i0 * kThreadsAll < PCH; i0 += XB) {
@@ -389,34 +392,59 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
     for (int st = 0; st < NS; ++st) {
       const char* const Wt = wbuf + (st & 1) * W_BYTES;
       const int left = nA - st * TPS, nstep = left >= TPS ? STEPS : (left + 3) >> 2;
+      // (step, column group) units in a software pipeline, as in bt_fused_split.h: the stage's tap offsets are fetched first,
+      // the fragments of unit u+1 are read before the MFMAs of unit u.
+      int eA[STEPS], eB[STEPS];  // this lane half's two taps of every step
+#pragma unroll
+      for (int q = 0; q < STEPS; ++q) eA[q] = eofftab[st * TPS + 4 * q + 2 * lh], eB[q] = eofftab[st * TPS + 4 * q + 2 * lh + 1];
+      bf16x8 wf[2][TN][NP];
+      uint2 xlo[2][NP], xhi[2][NP];
+      auto read_w = [&](int q) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) wf[q & 1][i][p] = *reinterpret_cast<const bf16x8*>(Wt + wlq[q] + q * W_STEP + p * W_PIECE + i * 32 * 16);
+      };
+      auto read_x = [&](int u) {
+        const int q = u / TM, j = u % TM;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          xlo[u & 1][p] = *reinterpret_cast<const uint2*>(xq + colq[j] + eA[q] + 8 * p);
+          xhi[u & 1][p] = *reinterpret_cast<const uint2*>(xq + colq[j] + eB[q] + 8 * p);
+        }
+      };
+      read_w(0);
+      read_x(0);
 #pragma unroll
       for (int q = 0; q < STEPS; ++q) {
         if (q < nstep) {  // uniform
-          const int eA = eofftab[st * TPS + 4 * q + 2 * lh], eB = eofftab[st * TPS + 4 * q + 2 * lh + 1];  // this lane half's two taps
-          bf16x8 wf[TN][NP];
-#pragma unroll
-          for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int p = 0; p < NP; ++p) wf[i][p] = *reinterpret_cast<const bf16x8*>(Wt + wlq[q] + q * W_STEP + p * W_PIECE + i * 32 * 16);
 #pragma unroll
           for (int j = 0; j < TM; ++j) {
-            bf16x8 xf[NP];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-              const uint2 lo = *reinterpret_cast<const uint2*>(xq + colq[j] + eA + 8 * p), hi = *reinterpret_cast<const uint2*>(xq + colq[j] + eB + 8 * p);
-              xf[p] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-            }
-#pragma unroll
-            for (int i = 0; i < TN; ++i) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[i][0], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[i][1], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], wf[i][0], acc[i][j], 0, 0, 0);
-              if constexpr (NP == 3) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[i][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], wf[i][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[2], wf[i][0], acc[i][j], 0, 0, 0);
+            const int u = q * TM + j;
+            if (j + 1 < TM) {
+              read_x(u + 1);
+            } else if (q + 1 < STEPS) {
+              if (q + 1 < nstep) {
+                read_x(u + 1);
+                read_w(q + 1);
               }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 xf[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) xf[p] = __builtin_bit_cast(bf16x8, make_uint4(xlo[u & 1][p].x, xlo[u & 1][p].y, xhi[u & 1][p].x, xhi[u & 1][p].y));
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[q & 1][i][0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[q & 1][i][1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], wf[q & 1][i][0], acc[i][j], 0, 0, 0);
+              if constexpr (NP == 3) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[q & 1][i][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], wf[q & 1][i][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[2], wf[q & 1][i][0], acc[i][j], 0, 0, 0);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
