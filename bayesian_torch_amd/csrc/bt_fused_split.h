@@ -73,8 +73,11 @@ __device__ __forceinline__ int div_small(int n, int d) { return d == 1 ? n : d =
 //   1: 1x1 input planes (and Linear): item = (image, octet), its 8 channels are 32 contiguous bytes.
 //   2: 2x2 input planes wholly inside the patch: item = (image, channel pair) -- a channel's plane is 16 contiguous bytes and
 //      consecutive lanes take consecutive channels, so a wave's loads cover whole 256-byte pieces of an image.
-//   3: stride-1 tiles of whole rows with W % 4 == 0: item = (4 consecutive input pixels, half an octet): 16-byte row pieces;
-//      the zero halo of the patch is never written (the buffers are cleared once).
+//   3: tiles of whole rows with W % 4 == 0 whose patch keeps every column of its rows (stride 1, or a strided 3x3 -- the patch
+//      of a strided window is the stride-1 grid): item = (4 consecutive input pixels, half an octet): 16-byte row pieces.
+//   4: the same for a patch that keeps every SECOND column (1x1 / stride 2: the downsamples): item = (4 consecutive input
+//      pixels, octet) = 2 patch pixels x 8 channels. (A dword gather at stride 2 costs the texture path ~70 cycles per wave
+//      instruction against 16 for a contiguous 16-byte one: 9.4 K -> 2 K cycles per stage on ResNet18's downsamples.)
 //
 // FLIP: the Flipout forward  out = x*mu + s_out o ((x o s_in) * (sigma o eps))  (flipout_layers.py:conv / linear forward): two
 // contractions that share the x pieces. The producers stage mu and sigma*eps as two weight images and, next to the pieces of
@@ -356,12 +359,13 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     if (NS > 0) load_w(0);  // stage 0's weight loads fly while the x items are decoded
     // x items of this thread (see XM above): global byte offset of the item at octet 0, LDS byte offset inside an x buffer,
     // octet inside the stage.
-    constexpr int PIT = XM == 3 ? ((XPO - 1) / 2 + kProducers - 1) / kProducers : (XPO - 1 + kProducers - 1) / kProducers;   // (XPO - 1 patch slots + the zero pixel)
-    constexpr int XV = XM == 3 ? 16 : 8;
+    constexpr int PIT = (XM == 3 || XM == 4) ? ((XPO - 1) / 2 + kProducers - 1) / kProducers : (XPO - 1 + kProducers - 1) / kProducers;   // (XPO - 1 patch slots + the zero pixel)
+    constexpr int XV = XM == 3 ? 16 : XM == 4 ? 32 : 8;
     int it_off[PIT], it_lds[PIT], it_ol[PIT];
     // real input rows of the patch and 16-byte quads per row (XM 3)
-    const int ylo_r = y_lo + kmin_h * gs_h, nyr = NYR, W4 = a.W >> 2;   // (XM 3: gs == 1, the stored columns are the whole row: NXR == W)
-    const int per_oct = XM == 2 ? 4 * t_NI : XM == 3 ? 2 * t_NI * nyr * W4 : PCH;   // XM 2: (image, channel pair) items
+    const int ylo_r = y_lo + kmin_h * gs_h, nyr = NYR, W4 = a.W >> 2;   // (XM 3: the stored columns are the whole row, NXR == W; XM 4: every second one)
+    const int xpar = (x_lo + kmin_w * gs_w) & 1;                          // XM 4: parity of the stored columns
+    const int per_oct = XM == 2 ? 4 * t_NI : XM == 3 ? 2 * t_NI * nyr * W4 : XM == 4 ? t_NI * nyr * W4 : PCH;   // XM 2: (image, channel pair) items
     const int n_items = NO * per_oct;
     {
       const uint32_t inv_per = per_oct > 1 ? inv32(per_oct) : 0u;
@@ -404,9 +408,17 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
           const int rem = q - img * qpi;
           const int yr = W4 <= 1 ? rem : (int)__umulhi((uint32_t)rem, inv_w4);
           const int xq = rem - yr * W4;
-          const int b = b0 + img, y = ylo_r + yr, x = 4 * xq;
-          lds = (ol * PCH + img * PIMG + (y - ylo_r) * NXR + x) * PB + hc * 8;
+          const int b = b0 + img, y = ylo_r + yr * gs_h, x = 4 * xq;
+          lds = (ol * PCH + img * PIMG + yr * NXR + x) * PB + hc * 8;
           if (b < a.B) off = 4 * ((b * a.Ci + g * Cig + 4 * hc) * a.HW + y * a.W + x);
+        } else if constexpr (XM == 4) {
+          const int img = qpi <= 1 ? r : (int)__umulhi((uint32_t)r, inv_qpi);
+          const int rem = r - img * qpi;
+          const int yr = W4 <= 1 ? rem : (int)__umulhi((uint32_t)rem, inv_w4);
+          const int xq = rem - yr * W4;
+          const int b = b0 + img, y = ylo_r + yr * gs_h, x = 4 * xq;
+          lds = (ol * PCH + img * PIMG + yr * NXR + 2 * xq) * PB;
+          if (b < a.B) off = 4 * ((b * a.Ci + g * Cig) * a.HW + y * a.W + x);
         } else {
           const int img = PIMG <= 1 ? r : (int)__umulhi((uint32_t)r, inv_pimg);
           const int rem = r - img * PIMG;
@@ -448,6 +460,12 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
           } else if constexpr (XM == 3) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+              const float4 v = ldf4(r_x, in ? (uint32_t)(it_off[i] + (8 * oc + c) * HWb) : kOOB);
+              xv[i][4 * c] = v.x, xv[i][4 * c + 1] = v.y, xv[i][4 * c + 2] = v.z, xv[i][4 * c + 3] = v.w;
+            }
+          } else if constexpr (XM == 4) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
               const float4 v = ldf4(r_x, in ? (uint32_t)(it_off[i] + (8 * oc + c) * HWb) : kOOB);
               xv[i][4 * c] = v.x, xv[i][4 * c + 1] = v.y, xv[i][4 * c + 2] = v.z, xv[i][4 * c + 3] = v.w;
             }
@@ -509,6 +527,14 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
                 for (int c = 0; c < 4; ++c) sb[c] = sign_bit(e0 + (uint32_t)(c * a.HW + px));
                 *reinterpret_cast<uint2*>(dst + px * PB + 16 * NP) = make_uint2(pack_hi16(sb[1], sb[0]), pack_hi16(sb[3], sb[2]));
               }
+            }
+          } else if constexpr (XM == 4) {  // input pixels xpar and xpar + 2 of the quad: two patch pixels x 8 channels
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              float v[8];
+#pragma unroll
+              for (int c = 0; c < 8; ++c) v[c] = xpar ? xv[i][4 * c + 2 * k + 1] : xv[i][4 * c + 2 * k];
+              store_px(dst + k * PB, v, e0 + (uint32_t)(2 * k + xpar), (uint32_t)a.HW);
             }
           } else {
             const float v[8] = {xv[i][0], xv[i][1], xv[i][2], xv[i][3], xv[i][4], xv[i][5], xv[i][6], xv[i][7]};

@@ -50,6 +50,7 @@ static int launch_split_xm(FwdArgs& a, int mode, int xm, hipStream_t stream) {
     if (xm == 2) return launch_split_cfg<BM, 3, NPW, 2>(a, stream);
   } else {
     if (xm == 3) return launch_split_cfg<BM, 3, NPW, 3>(a, stream);
+    if (xm == 4) return launch_split_cfg<BM, 3, NPW, 4>(a, stream);
   }
   return launch_split_cfg<BM, 3, NPW, 0>(a, stream);
 }
@@ -145,7 +146,7 @@ static int launch_split_one(FwdArgs& a, hipStream_t stream) {
   const bool xal = (((uintptr_t)a.x) & 15u) == 0 && (a.x_sample_stride & 3) == 0;
   int xm = 0;
   if (xal && a.HW == 1) xm = 1;
-  else if (xal && bm != 128 && !a.pixel_major && a.HW > 1 && a.SH == 1 && a.SW == 1 && (a.W & 3) == 0 && a.t_Wt == a.Wo && split_rows_cover(a)) xm = 3;
+  else if (xal && bm != 128 && !a.pixel_major && a.HW > 1 && (a.W & 3) == 0 && a.t_Wt == a.Wo && split_row_mode(a)) xm = split_row_mode(a);
   else if (xal && a.pixel_major && a.H == 2 && a.W == 2 && a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.SH == 1 && a.SW == 1 && a.DH == 1 && a.DW == 1) xm = 2;
   if (bm == 512) return launch_split_xm<512, 4>(a, mode, xm, stream);
   if (bm == 256) return launch_split_xm<256, 4>(a, mode, xm, stream);

@@ -50,18 +50,27 @@ static void tap_window(int K, int D, int S, int P, int In, int Out, bool per_pix
   *n_act = best_n, *extent = best_ext;
 }
 
-// Stride-1 tiles of whole output rows: does the patch (window of the active taps) cover every column of the input rows? Then
-// the halo of the patch is zero padding only and the x fetch can move whole 16-byte row pieces (XM 3).
-static bool split_rows_cover(const FwdArgs& a) {
+// Tiles of whole output rows (t_Wt == Wo): which columns of its input rows does the patch keep (the kernel's own rule,
+// bt_fused_split.h: the window of the active taps on a grid of spacing gs = 1, or the stride when a single tap column is
+// active)? 3: every column (the x fetch can move 16-byte row pieces, XM 3), 4: every second column (XM 4), 0: neither.
+static int split_row_mode(const FwdArgs& a) {
   int lo = 1 << 30, hi = -1;
   for (int k = 0; k < a.KW; ++k) {
-    const int l = a.PW - k * a.DW, c = l > 0 ? l : 0;  // stride 1
-    if (c < a.Wo && c - l < a.W) lo = k * a.DW < lo ? k * a.DW : lo, hi = k * a.DW > hi ? k * a.DW : hi;
+    const int l = a.PW - k * a.DW, c = l > 0 ? (l + a.SW - 1) / a.SW : 0;
+    if (c < a.Wo && c * a.SW - l < a.W) lo = k * a.DW < lo ? k * a.DW : lo, hi = k * a.DW > hi ? k * a.DW : hi;
   }
-  if (hi < 0) return false;
-  const int x_lo = -a.PW + lo, x_hi = (a.Wo - 1) - a.PW + hi;  // first / last input column of the patch
-  return x_lo <= 0 && x_hi >= a.W - 1;
+  if (hi < 0) return 0;
+  const int dxs = hi - lo, gs = dxs ? 1 : a.SW, ps = dxs ? a.SW : 1;
+  if (gs > 2 || (a.W & 3)) return 0;
+  const int x_lo = -a.PW + lo, PWt = (a.Wo - 1) * ps + dxs + 1;
+  const int kmin = x_lo < 0 ? (-x_lo + gs - 1) / gs : 0;
+  int kmax = a.W - 1 - x_lo >= 0 ? (a.W - 1 - x_lo) / gs : -1;
+  if (kmax > PWt - 1) kmax = PWt - 1;
+  const int NXR = kmax >= kmin ? kmax - kmin + 1 : 0;
+  if (gs == 1) return NXR == a.W ? 3 : 0;
+  return NXR == a.W / 2 ? 4 : 0;
 }
+static bool split_rows_cover(const FwdArgs& a) { return split_row_mode(a) == 3; }
 
 // Tile geometry as bt_fused_dispatch.h's fast_geometry, with the split flavour's capacity: the patch of ONE octet plane has to
 // fit XPO pixels. Fills the tile fields and returns the tile's live columns (0: does not fit).
