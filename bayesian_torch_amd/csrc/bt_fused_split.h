@@ -363,7 +363,9 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     constexpr int XV = XM == 3 ? 16 : XM == 4 ? 32 : 8;
     int it_off[PIT], it_lds[PIT], it_ol[PIT];
     // real input rows of the patch and 16-byte quads per row (XM 3)
-    const int ylo_r = y_lo + kmin_h * gs_h, nyr = NYR, W4 = a.W >> 2;   // (XM 3: the stored columns are the whole row, NXR == W; XM 4: every second one)
+    // (XM 3: the stored columns are the whole row, NXR == W -- or, x_flat, the whole plane taken as ONE row of H*W pixels; XM 4: every second column)
+    const bool flat = XM == 3 && a.x_flat != 0;
+    const int ylo_r = y_lo + kmin_h * gs_h, nyr = flat ? 1 : NYR, W4 = flat ? a.HW >> 2 : a.W >> 2;
     const int xpar = (x_lo + kmin_w * gs_w) & 1;                          // XM 4: parity of the stored columns
     const int per_oct = XM == 2 ? 4 * t_NI : XM == 3 ? 2 * t_NI * nyr * W4 : XM == 4 ? t_NI * nyr * W4 : PCH;   // XM 2: (image, channel pair) items
     const int n_items = NO * per_oct;

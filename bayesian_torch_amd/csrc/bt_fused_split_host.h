@@ -50,27 +50,43 @@ static void tap_window(int K, int D, int S, int P, int In, int Out, bool per_pix
   *n_act = best_n, *extent = best_ext;
 }
 
-// Tiles of whole output rows (t_Wt == Wo): which columns of its input rows does the patch keep (the kernel's own rule,
-// bt_fused_split.h: the window of the active taps on a grid of spacing gs = 1, or the stride when a single tap column is
-// active)? 3: every column (the x fetch can move 16-byte row pieces, XM 3), 4: every second column (XM 4), 0: neither.
-static int split_row_mode(const FwdArgs& a) {
+// One axis of a tile that spans the whole output axis: how many input positions does the patch keep (the kernel's own rule,
+// bt_fused_split.h: the window of the active taps on a grid of spacing gs = 1, or the stride when a single tap is active)?
+static int split_axis_kept(int K, int D, int S, int P, int In, int Out, int* gs_out) {
   int lo = 1 << 30, hi = -1;
-  for (int k = 0; k < a.KW; ++k) {
-    const int l = a.PW - k * a.DW, c = l > 0 ? (l + a.SW - 1) / a.SW : 0;
-    if (c < a.Wo && c * a.SW - l < a.W) lo = k * a.DW < lo ? k * a.DW : lo, hi = k * a.DW > hi ? k * a.DW : hi;
+  for (int k = 0; k < K; ++k) {
+    const int l = P - k * D, c = l > 0 ? (l + S - 1) / S : 0;
+    if (c < Out && c * S - l < In) lo = k * D < lo ? k * D : lo, hi = k * D > hi ? k * D : hi;
   }
+  *gs_out = 1;
   if (hi < 0) return 0;
-  const int dxs = hi - lo, gs = dxs ? 1 : a.SW, ps = dxs ? a.SW : 1;
-  if (gs > 2 || (a.W & 3)) return 0;
-  const int x_lo = -a.PW + lo, PWt = (a.Wo - 1) * ps + dxs + 1;
+  const int ext = hi - lo, gs = ext ? 1 : S, ps = ext ? S : 1;
+  const int x_lo = -P + lo, Pt = (Out - 1) * ps + ext + 1;
   const int kmin = x_lo < 0 ? (-x_lo + gs - 1) / gs : 0;
-  int kmax = a.W - 1 - x_lo >= 0 ? (a.W - 1 - x_lo) / gs : -1;
-  if (kmax > PWt - 1) kmax = PWt - 1;
-  const int NXR = kmax >= kmin ? kmax - kmin + 1 : 0;
-  if (gs == 1) return NXR == a.W ? 3 : 0;
-  return NXR == a.W / 2 ? 4 : 0;
+  int kmax = In - 1 - x_lo >= 0 ? (In - 1 - x_lo) / gs : -1;
+  if (kmax > Pt - 1) kmax = Pt - 1;
+  *gs_out = gs;
+  return kmax >= kmin ? kmax - kmin + 1 : 0;
+}
+// Tiles of whole output rows (t_Wt == Wo): which columns of its input rows does the patch keep? 3: every column (the x fetch can
+// move 16-byte row pieces, XM 3), 4: every second column (XM 4), 0: neither / W % 4 != 0.
+static int split_row_mode(const FwdArgs& a) {
+  int gs;
+  const int kept = split_axis_kept(a.KW, a.DW, a.SW, a.PW, a.W, a.Wo, &gs);
+  if (gs > 2 || (a.W & 3)) return 0;
+  if (gs == 1) return kept == a.W ? 3 : 0;
+  return kept == a.W / 2 ? 4 : 0;
 }
 static bool split_rows_cover(const FwdArgs& a) { return split_row_mode(a) == 3; }
+// Tiles of whole images whose patch is the whole input plane (every row, every column): a plane is then one contiguous run of
+// H*W floats in memory AND in the patch, so with H*W % 4 == 0 the 16-byte fetch of XM 3 works on the flattened plane whatever
+// W is (ResNet50's 14x14 maps).
+static bool split_plane_flat(const FwdArgs& a) {
+  if ((a.HW & 3) || a.t_R != a.Ho || a.t_Wt != a.Wo) return false;
+  int gh, gw;
+  const int kh = split_axis_kept(a.KH, a.DH, a.SH, a.PH, a.H, a.Ho, &gh), kw = split_axis_kept(a.KW, a.DW, a.SW, a.PW, a.W, a.Wo, &gw);
+  return gh == 1 && gw == 1 && kh == a.H && kw == a.W;
+}
 
 // Tile geometry as bt_fused_dispatch.h's fast_geometry, with the split flavour's capacity: the patch of ONE octet plane has to
 // fit XPO pixels. Fills the tile fields and returns the tile's live columns (0: does not fit).

@@ -28,6 +28,10 @@ GEOMS = {
     "layer3.0.conv1 128->256 3x3 s2 4x4->2x2 (pixel-major, generic fetch)": (128, 256, (3, 3), 2, 1, 1, 1, 4, 4, 128, 2, True),
     "layer4.0.downsample 256->512 1x1 s2 2x2->1x1": (256, 512, (1, 1), 2, 0, 1, 1, 2, 2, 128, 2, False),
     "1x1 maps, partial batch tile (B = 120)": (64, 96, (3, 3), 1, 1, 1, 1, 1, 1, 120, 1, True),
+    "14x14 maps 3x3 (W % 4 != 0: whole planes fetched flat)": (64, 64, (3, 3), 1, 1, 1, 1, 14, 14, 16, 2, True),
+    "14x14 maps 1x1 256->64 (flat planes, one tap)": (256, 64, (1, 1), 1, 0, 1, 1, 14, 14, 8, 2, False),
+    "28x28 -> 14x14 1x1 s2 (every second column, XM 4)": (64, 128, (1, 1), 2, 0, 1, 1, 28, 28, 8, 2, True),
+    "28x28 -> 14x14 3x3 s2 (strided window: row quads)": (32, 64, (3, 3), 2, 1, 1, 1, 28, 28, 8, 2, False),
 }
 
 
