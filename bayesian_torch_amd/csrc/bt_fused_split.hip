@@ -79,24 +79,35 @@ static int launch_quad_cfg(FwdArgs& a, int mode, hipStream_t stream) {
 }
 
 static int launch_quad(FwdArgs& a, int mode, hipStream_t stream) {
-  if (a.pixel_major || a.T > 64 || !a.out_vec4 || a.HoWo > 512 || a.HoWo < 2) return 1;
+  if (a.pixel_major || a.T > 64 || !a.out_vec4 || a.HoWo < 2 || a.Wo > 512) return 1;
   int nh, nw, dys, dxs;
   tap_window(a.KH, a.DH, a.SH, a.PH, a.H, a.Ho, false, &nh, &dys);
   tap_window(a.KW, a.DW, a.SW, a.PW, a.W, a.Wo, false, &nw, &dxs);
-  const long long PHt = (long long)(a.Ho - 1) * (dys ? a.SH : 1) + dys + 1, PWt = (long long)(a.Wo - 1) * (dxs ? a.SW : 1) + dxs + 1;
-  int NI = 512 / a.HoWo;
-  if (NI > a.B) NI = a.B;
   constexpr long long XCAP = kQuadXBytes / 24;
-  while (NI > 1 && NI * PHt * PWt > XCAP) --NI;
-  if (NI * PHt * PWt > XCAP) return 1;
-  const long long n_bt = (a.B + NI - 1) / NI;
-  if ((double)a.M / ((double)n_bt * 512) < 0.75) return 1;   // the wide tile must be filled
+  const long long PWt = (long long)(a.Wo - 1) * (dxs ? a.SW : 1) + dxs + 1;
+  int NI, R;
+  long long tiles_per_sample;
+  if (a.HoWo <= 512) {   // whole images
+    const long long PHt = (long long)(a.Ho - 1) * (dys ? a.SH : 1) + dys + 1;
+    NI = 512 / a.HoWo, R = a.Ho;
+    if (NI > a.B) NI = a.B;
+    while (NI > 1 && NI * PHt * PWt > XCAP) --NI;
+    if (NI * PHt * PWt > XCAP) return 1;
+    tiles_per_sample = (a.B + NI - 1) / NI;
+  } else {               // a band of whole rows of one image (ImageNet stems: 112 x 112 outputs -> 4 rows per tile)
+    if (a.ep_pool) return 1;   // (the pooled read-out needs whole images: the caller pools in a separate pass)
+    NI = 1, R = 512 / a.Wo;
+    while (R > 1 && ((long long)(R - 1) * (dys ? a.SH : 1) + dys + 1) * PWt > XCAP) --R;
+    if (((long long)(R - 1) * (dys ? a.SH : 1) + dys + 1) * PWt > XCAP) return 1;
+    tiles_per_sample = (long long)a.B * ((a.Ho + R - 1) / R);
+  }
+  if ((double)a.M / ((double)tiles_per_sample * 512) < 0.75) return 1;   // the wide tile must be filled
   if (a.ep_pool) {
     const int Wp = a.ep_Wp;
     if ((Wp & (Wp - 1)) != 0 || Wp < 4 || Wp > 16 || a.ep_res) return 1;
   }
   a.n_tiles = (a.Cog + 63) / 64;
-  a.t_NI = NI, a.t_R = a.Ho, a.t_Wt = a.Wo, a.n_bt = (int)n_bt, a.n_rt = 1, a.n_ct = 1, a.m_tiles = (int)n_bt;
+  a.t_NI = NI, a.t_R = R, a.t_Wt = a.Wo, a.n_bt = (a.B + NI - 1) / NI, a.n_rt = (a.Ho + R - 1) / R, a.n_ct = 1, a.m_tiles = a.n_bt * a.n_rt;
   const long long total = (long long)a.G * a.n_tiles * a.S * a.m_tiles;
   if (total <= 0 || total > 0x7FFFFFFFll) return 1;
   a.total_blocks = (int)total;

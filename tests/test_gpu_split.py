@@ -212,6 +212,8 @@ STEMS = {
     "4 channels, 5x5 s1, bias, 40 output channels": (4, 40, (5, 5), 1, 2, 16, 16, 6, 1, True),
     "1 channel, 3x3": (1, 64, (3, 3), 1, 1, 16, 16, 4, 2, True),
     "2 channels, 7x7 s2 on 64x64 (one image per tile)": (2, 64, (7, 7), 2, 3, 32, 32, 3, 1, False),
+    "ImageNet-style stem 3->64 7x7 s2 on 96x96 (bands of 10 rows of 48)": (3, 64, (7, 7), 2, 3, 96, 96, 2, 2, True),
+    "3 channels, 3x3 s1 on 40x40 (bands of 12 rows, last band ragged)": (3, 32, (3, 3), 1, 1, 40, 40, 3, 1, False),
 }
 
 
