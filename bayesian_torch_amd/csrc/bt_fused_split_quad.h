@@ -17,25 +17,34 @@
 namespace bt {
 
 constexpr int kQuadXBytes = 2 * split_x_bytes<512, 3>();  // 98,304 B: 4096 pixels of 24 B
+constexpr int kQuadXBytesFlip = 38400;                     // Flipout: what two weight images leave: 1600 pixels of 24 B
+template <bool FLIP>
+constexpr int quad_lds_bytes() { return 2 * split_w_bytes<64, 3, FLIP>() + (FLIP ? kQuadXBytesFlip : kQuadXBytes) + kSplitMiscBytes; }
 
-template <int NP, bool POOL>
+// FLIP (Flipout, <= 3 input channels): as bt_fused_split.h's -- two weight images (mu | sigma*eps), two accumulator sets, 4 consumer
+// waves of 32 channels x 128 pixels (BM = 256), s_out in the output stage. The sign bits of a pixel's (<= 3) channels ride in
+// the PADDING channel of its first piece (bits 0-2 of that bf16: a denormal that only ever meets the zero weights of the padding
+// channel), so the patch stays 24 B per pixel and the 37x37 patch of a CIFAR stem fits beside the two weight images; a
+// consumer expands them to sign masks and flips its x fragments in registers between the two contractions.
+template <int NP, bool POOL, bool FLIP = false>
 __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) {
-  constexpr int BN = 64, BM = 512, kProducers = 256, kThreadsAll = 512, STEPS = kSplitSteps, TPS = 4 * STEPS;  // taps per stage
-  constexpr int CWM = 4, WTM = BM / CWM, TN = BN / 32, TM = WTM / 32;
+  constexpr int BN = 64, BM = FLIP ? 256 : 512, kProducers = 256, kThreadsAll = 512, STEPS = kSplitSteps, TPS = 4 * STEPS;  // taps per stage
+  constexpr int CWM = FLIP ? 2 : 4, CWN = 4 / CWM, WTM = BM / CWM, TN = BN / CWN / 32, TM = WTM / 32, NOP = FLIP ? 2 : 1;
   constexpr int PBQ = 8 * NP;  // bytes per pixel of the quad patch
-  constexpr int W_BYTES = split_w_bytes<BN, NP>(), X_BYTES = split_x_bytes<BM, NP>();
+  constexpr int W_BYTES = split_w_bytes<BN, NP, FLIP>(), W_OP = W_BYTES / NOP, XQ_BYTES = FLIP ? kQuadXBytesFlip : kQuadXBytes;
   constexpr int W_STEP = 2 * NP * BN * 16, W_HALF = NP * BN * 16, W_PIECE = BN * 16;
-  constexpr int XCAP = 2 * X_BYTES / PBQ;  // pixels
+  constexpr int XCAP = XQ_BYTES / PBQ;  // pixels
   constexpr int SROWS = BN, SROW = BM + 4;
-  static_assert((4 * BN + SROWS * SROW) * 4 <= 2 * (W_BYTES + X_BYTES), "output staging fits the operand buffers");
+  static_assert(!FLIP || NP == 3, "Flipout: the exact split");
+  static_assert((4 * BN + NOP * SROWS * SROW) * 4 <= 2 * W_BYTES + XQ_BYTES, "output staging fits the operand buffers");
   constexpr int kMaxChunks = (64 + TPS - 1) / TPS;  // T <= 64
 
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   char* const wbuf = smem_c;                  // [2][W_BYTES]
-  char* const xq = smem_c + 2 * W_BYTES;      // one patch, 2 * X_BYTES
+  char* const xq = smem_c + 2 * W_BYTES;      // one patch, XQ_BYTES
   float* const smem = reinterpret_cast<float*>(smem_c);
-  int4* const taptab = reinterpret_cast<int4*>(smem_c + 2 * (W_BYTES + X_BYTES));
-  double* const red = reinterpret_cast<double*>(smem_c + 2 * (W_BYTES + X_BYTES) + kMaxTaps * 16);
+  int4* const taptab = reinterpret_cast<int4*>(smem_c + 2 * W_BYTES + XQ_BYTES);
+  double* const red = reinterpret_cast<double*>(smem_c + 2 * W_BYTES + XQ_BYTES + kMaxTaps * 16);
   int* const misc = reinterpret_cast<int*>(red + 12);
   int* const eofftab = reinterpret_cast<int*>(taptab + 64);  // [chunk][step][4 taps]: byte offset of the tap inside the patch (T <= 64: upper half of the tap table's room)
   (void)red;
@@ -44,7 +53,7 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
   const bool producer = wave >= 4;
   const int ptid = producer ? tid - 256 : tid;
   const int li = lane & 31, lh = lane >> 5;
-  const int wm = wave & 3;
+  const int wm = wave & (CWM - 1), wn = (wave & 3) / CWM;
 
   int L = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, a.total_blocks));   // (reciprocals from the host: bt_fused_split_host.h)
   int Lq = udiv_inv(L, a.m_tiles, a.inv_m_tiles);
@@ -77,6 +86,14 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
   key_w.seed_hi = a.seed_hi;
   key_w.call = a.call + (a.call_base ? __builtin_nontemporal_load(a.call_base) : 0u);
   key_w.layer_tensor = layer_tensor_word(a.layer_id, 0);
+  uint32_t skey_in = 0, skey_out = 0;  // Flipout sign streams (bt_fused_fwd.h)
+  if constexpr (FLIP) {
+    RngKey ks = key_w;
+    ks.layer_tensor = layer_tensor_word(a.layer_id, 2);
+    skey_in = sign_stream_key(ks, sample);
+    ks.layer_tensor = layer_tensor_word(a.layer_id, 3);
+    skey_out = sign_stream_key(ks, sample);
+  }
 
   if (wave == 0) {  // active taps + their window
     bool act = false;
@@ -125,6 +142,7 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
   auto ldf4 = [](const __amdgpu_buffer_rsrc_t& r, uint32_t byte_off) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0)); };
 
   float* const bias0 = smem;
+  float* const bias1 = smem + BN;  // Flipout: the sigma*eps part of the bias
   float* const osc = smem + 2 * BN;
   float* const osh = smem + 3 * BN;
   const bool kl_block = a.do_kl && (int)blockIdx.x < a.kl_slices;
@@ -202,6 +220,34 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
     }
   };
 
+  // Flipout: the two staged accumulator sets -> one (s_out from the hash stream of the output element, then the output-stage
+  // constants, in the fp32 kernels' order), in place, by every wave; the read-outs above then see what the Reparameterization
+  // consumers would have staged.
+  auto combine_flip = [&](int t0) {
+    constexpr int QROW = BM / 4, RSTEP = kThreadsAll / QROW, NIT = SROWS / RSTEP;
+    static_assert(kThreadsAll % QROW == 0 && SROWS % RSTEP == 0, "a thread keeps its pixel quad");
+    float* const stage = smem + 4 * BN;
+    const int m4 = t0 % QROW, row0 = t0 / QROW;
+    int bq, hq, wq;
+    const bool mok = col_decode(4 * m4, bq, hq, wq);
+    const int HoWo_ = a.Ho * a.Wo;
+    const uint32_t obase = mok ? (uint32_t)(((bq * a.Co + g * a.Cog + n0 + row0) * a.Ho + hq) * a.Wo + wq) : 0u;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int row = row0 + k * RSTEP;
+      float* const p0 = stage + row * SROW + 4 * m4;
+      float4 v = *reinterpret_cast<const float4*>(p0);
+      const float4 d = *reinterpret_cast<const float4*>(p0 + SROWS * SROW);
+      const uint32_t oi = obase + (uint32_t)(k * RSTEP * HoWo_);
+      const float sc = osc[row], sh = osh[row];
+      v.x = __fadd_rn(__fmul_rn(__fadd_rn(v.x, __fmul_rn(d.x, hash_sign(skey_out, oi))), sc), sh);
+      v.y = __fadd_rn(__fmul_rn(__fadd_rn(v.y, __fmul_rn(d.y, hash_sign(skey_out, oi + 1u))), sc), sh);
+      v.z = __fadd_rn(__fmul_rn(__fadd_rn(v.z, __fmul_rn(d.z, hash_sign(skey_out, oi + 2u))), sc), sh);
+      v.w = __fadd_rn(__fmul_rn(__fadd_rn(v.w, __fmul_rn(d.w, hash_sign(skey_out, oi + 3u))), sc), sh);
+      *reinterpret_cast<float4*>(p0) = v;
+    }
+  };
+
 // ---- the patch, once, by ALL 8 waves (the consumers have nothing to do before the first stage): a thread owns pixels
 //      tid + 512 i; <= 4 channels per pixel, split on the way to LDS ----
   {
@@ -212,6 +258,7 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
     for (int i0 = 0; i0 * kThreadsAll < PCH; i0 += XB) {
       float xv[XB][4];
       int pos_[XB];
+      uint32_t xoff_[XB];
 #pragma unroll
       for (int k = 0; k < XB; ++k) {
         const int pos = tid + kThreadsAll * (i0 + k);
@@ -224,6 +271,7 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
         const int b = b0 + img, y = y_lo + yy * gs_h, x = x_lo + xx * gs_w;
         const bool ok = pos < PCH && b < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
         const uint32_t off = ok ? (uint32_t)(4 * ((b * a.Ci + g * Cig) * a.HW + y * a.W + x)) : kOOB;
+        xoff_[k] = ok ? off : 0u;
 #pragma unroll
         for (int c = 0; c < 4; ++c) xv[k][c] = ldf(r_x, (ok && c < Cig) ? off + (uint32_t)(c * HWb) : kOOB);
       }
@@ -233,6 +281,13 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
           uint32_t ph[4], pm[4], pl[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) split_pieces(xv[k][c], ph[c], pm[c], pl[c]);
+          if constexpr (FLIP) {  // s_in of channels 0..2 (hash of the element's offset in the sample's x) -> bits 16..18: the padding channel's lane
+            uint32_t bits = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              bits |= (__float_as_uint(hash_sign(skey_in, (xoff_[k] >> 2) + (uint32_t)(c * a.HW))) >> 31) << (16 + c);
+            ph[3] = bits;
+          }
           char* const dst = xq + pos_[k] * PBQ;
           *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(ph[1], ph[0]), pack_hi16(ph[3], ph[2]));
           *reinterpret_cast<uint2*>(dst + 8) = make_uint2(pack_hi16(pm[1], pm[0]), pack_hi16(pm[3], pm[2]));
@@ -281,11 +336,18 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
           uint32_t wh[4], wm_[4], wl[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j)  // masked units (dead taps, rows past Cog) loaded zeros: w = 0 -- and the slot IS written
-            split_pieces(__fadd_rn(m4[j], __fmul_rn(s4[j], ep[i][j])), wh[j], wm_[j], wl[j]);
+            split_pieces(FLIP ? m4[j] : __fadd_rn(m4[j], __fmul_rn(s4[j], ep[i][j])), wh[j], wm_[j], wl[j]);
           char* const dst = Wt + l_off[i];
           *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(wh[1], wh[0]), pack_hi16(wh[3], wh[2]));
           *reinterpret_cast<uint2*>(dst + W_PIECE) = make_uint2(pack_hi16(wm_[1], wm_[0]), pack_hi16(wm_[3], wm_[2]));
           if constexpr (NP == 3) *reinterpret_cast<uint2*>(dst + 2 * W_PIECE) = make_uint2(pack_hi16(wl[1], wl[0]), pack_hi16(wl[3], wl[2]));
+          if constexpr (FLIP) {  // second image: the perturbation sigma * eps
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_pieces(__fmul_rn(s4[j], ep[i][j]), wh[j], wm_[j], wl[j]);
+            *reinterpret_cast<uint2*>(dst + W_OP) = make_uint2(pack_hi16(wh[1], wh[0]), pack_hi16(wh[3], wh[2]));
+            *reinterpret_cast<uint2*>(dst + W_OP + W_PIECE) = make_uint2(pack_hi16(wm_[1], wm_[0]), pack_hi16(wm_[3], wm_[2]));
+            *reinterpret_cast<uint2*>(dst + W_OP + 2 * W_PIECE) = make_uint2(pack_hi16(wl[1], wl[0]), pack_hi16(wl[3], wl[2]));
+          }
         }
         if (st + 1 < NS) load_w(st + 1);
       }
@@ -302,7 +364,11 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
         philox_normal4(kb, sample, (uint32_t)(co >> 2), z);
         const int sel = co & 3;
         const float e = sel == 0 ? z[0] : sel == 1 ? z[1] : sel == 2 ? z[2] : z[3];
-        bv = __fadd_rn(a.mu_b[co], __fmul_rn(softplus(a.rho_b[co]), e));
+        const float dl = __fmul_rn(softplus(a.rho_b[co]), e);
+        bv = FLIP ? a.mu_b[co] : __fadd_rn(a.mu_b[co], dl);
+        if constexpr (FLIP) bias1[ptid] = dl;
+      } else if constexpr (FLIP) {
+        bias1[ptid] = 0.f;
       }
       bias0[ptid] = bv;
       const bool cv = a.ep_scale && co_g < a.Cog;
@@ -314,6 +380,10 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();
+    if constexpr (FLIP) {
+      combine_flip(tid);
+      __syncthreads();
+    }
     if constexpr (POOL) readout_pool(wave);
     else readout_quads(tid);
   } else {
@@ -378,15 +448,17 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
     }
     int wlq[STEPS];
 #pragma unroll
-    for (int q = 0; q < STEPS; ++q) wlq[q] = lh * W_HALF + (li ^ ((2 * q + lh) & 7)) * 16;
+    for (int q = 0; q < STEPS; ++q) wlq[q] = lh * W_HALF + (li ^ ((2 * q + lh) & 7)) * 16 + wn * TN * 32 * 16;
 
-    f32x16 acc[TN][TM];
+    f32x16 acc[NOP][TN][TM];
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int o = 0; o < NOP; ++o)
 #pragma unroll
-      for (int j = 0; j < TM; ++j)
+      for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[o][i][j][r] = 0.f;
 
     __syncthreads();  // patch and stage 0 staged
     for (int st = 0; st < NS; ++st) {
@@ -397,13 +469,16 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
       int eA[STEPS], eB[STEPS];  // this lane half's two taps of every step
 #pragma unroll
       for (int q = 0; q < STEPS; ++q) eA[q] = eofftab[st * TPS + 4 * q + 2 * lh], eB[q] = eofftab[st * TPS + 4 * q + 2 * lh + 1];
-      bf16x8 wf[2][TN][NP];
+      bf16x8 wf[2][NOP][TN][NP];
       uint2 xlo[2][NP], xhi[2][NP];
       auto read_w = [&](int q) {
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+        for (int o = 0; o < NOP; ++o)
 #pragma unroll
-          for (int p = 0; p < NP; ++p) wf[q & 1][i][p] = *reinterpret_cast<const bf16x8*>(Wt + wlq[q] + q * W_STEP + p * W_PIECE + i * 32 * 16);
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+              wf[q & 1][o][i][p] = *reinterpret_cast<const bf16x8*>(Wt + o * W_OP + wlq[q] + q * W_STEP + p * W_PIECE + i * 32 * 16);
       };
       auto read_x = [&](int u) {
         const int q = u / TM, j = u % TM;
@@ -434,14 +509,28 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
 #pragma unroll
             for (int p = 0; p < NP; ++p) xf[p] = __builtin_bit_cast(bf16x8, make_uint4(xlo[u & 1][p].x, xlo[u & 1][p].y, xhi[u & 1][p].x, xhi[u & 1][p].y));
 #pragma unroll
-            for (int i = 0; i < TN; ++i) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[q & 1][i][0], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[q & 1][i][1], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], wf[q & 1][i][0], acc[i][j], 0, 0, 0);
-              if constexpr (NP == 3) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[q & 1][i][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], wf[q & 1][i][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[2], wf[q & 1][i][0], acc[i][j], 0, 0, 0);
+            for (int o = 0; o < NOP; ++o) {
+              if (o == 1) {  // Flipout: x o s_in. The sign bits of a pixel's channels 0..2 sit in bits 16..18 of its first piece's second dword
+                const uint32_t mA = xlo[u & 1][0].y, mB = xhi[u & 1][0].y;
+                const uint4 mk = make_uint4(((mA & 0x10000u) >> 1) | ((mA & 0x20000u) << 14), (mA & 0x40000u) >> 3,
+                                            ((mB & 0x10000u) >> 1) | ((mB & 0x20000u) << 14), (mB & 0x40000u) >> 3);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                  uint4 t = __builtin_bit_cast(uint4, xf[p]);
+                  t.x ^= mk.x, t.y ^= mk.y, t.z ^= mk.z, t.w ^= mk.w;
+                  xf[p] = __builtin_bit_cast(bf16x8, t);
+                }
+              }
+#pragma unroll
+              for (int i = 0; i < TN; ++i) {
+                acc[o][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[q & 1][o][i][0], acc[o][i][j], 0, 0, 0);
+                acc[o][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[q & 1][o][i][1], acc[o][i][j], 0, 0, 0);
+                acc[o][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], wf[q & 1][o][i][0], acc[o][i][j], 0, 0, 0);
+                if constexpr (NP == 3) {
+                  acc[o][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wf[q & 1][o][i][2], acc[o][i][j], 0, 0, 0);
+                  acc[o][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], wf[q & 1][o][i][1], acc[o][i][j], 0, 0, 0);
+                  acc[o][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[2], wf[q & 1][o][i][0], acc[o][i][j], 0, 0, 0);
+                }
               }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -457,27 +546,41 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
 
     // ---- output stage: the whole tile through LDS (lane = one channel, registers 4q..4q+3 = 4 consecutive positions) ----
     float* const stage = smem + 4 * BN;
-    float bsv[TN], scv[TN], shv[TN];
+    float bsv[TN], scv[TN], shv[TN], b1v[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-      const int co_l = i * 32 + li;
+      const int co_l = (wn * TN + i) * 32 + li;
       bsv[i] = bias0[co_l], scv[i] = osc[co_l], shv[i] = osh[co_l];
+      b1v[i] = FLIP ? bias1[co_l] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-      float* const srow = stage + (i * 32 + li) * SROW + wm * WTM + 4 * lh;
+      float* const srow = stage + ((wn * TN + i) * 32 + li) * SROW + wm * WTM + 4 * lh;
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float v[4];
+          if constexpr (FLIP) {  // both sets as they are (+ their bias parts): combine_flip joins them
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(__fmul_rn(__fadd_rn(acc[i][j][4 * q + e], bsv[i]), scv[i]), shv[i]);
-          *reinterpret_cast<float4*>(srow + j * 32 + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+            for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(acc[0][i][j][4 * q + e], bsv[i]);
+            *reinterpret_cast<float4*>(srow + j * 32 + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(acc[NOP - 1][i][j][4 * q + e], b1v[i]);
+            *reinterpret_cast<float4*>(srow + SROWS * SROW + j * 32 + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(__fmul_rn(__fadd_rn(acc[0][i][j][4 * q + e], bsv[i]), scv[i]), shv[i]);
+            *reinterpret_cast<float4*>(srow + j * 32 + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+          }
         }
       }
     }
     __syncthreads();
+    if constexpr (FLIP) {
+      combine_flip(tid);
+      __syncthreads();
+    }
     if constexpr (POOL) readout_pool(wave);
     else readout_quads(tid);
   }

@@ -303,7 +303,7 @@ def test_fast_kernel_tile_geometries_vs_oracle(Ci, Co, k, st, pd, H, W, B, flip)
 @pytest.mark.gpu
 @pytest.mark.parametrize("Ci,Co,k,st,pd,H,W,B,flip,fusable", [
     (3, 64, 7, 2, 3, 32, 32, 6, False, True),     # the CIFAR ResNet stem: two 16x16 images per 512-wide tile
-    (3, 24, 7, 2, 3, 32, 32, 5, True, False),     # Flipout has no tile wider than 128 positions: 16x16 images -> separate pass
+    (3, 24, 7, 2, 3, 32, 32, 5, True, True),      # the Flipout stem: one 16x16 image per 256-wide tile of the split quad flavour
     (6, 24, 3, 1, 1, 8, 8, 5, True, False),       # Flipout stages x through registers (no row-chunk kernel): separate pass
     (6, 24, 3, 1, 1, 8, 8, 5, False, True),       # 8x8 images, channel count that is not a tile multiple, ragged batch
     (8, 16, 3, 1, 1, 12, 8, 3, False, True),      # non-square, even sizes

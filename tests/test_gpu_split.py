@@ -366,3 +366,61 @@ def test_split_flipout_is_independent_of_launch_split():
     a, _, _ = _run_flip(mu, rho, mb, rb, x4[:2 * B], conv, 2, 0, sample0=5)
     b, _, _ = _run_flip(mu, rho, mb, rb, x4[2 * B:], conv, 2, 0, sample0=7)
     assert torch.equal(torch.cat([a, b]), full)
+
+
+FLIP_STEMS = {
+    "flip CIFAR stem 3->64 7x7 s2 on 32x32 (one image per 256 tile)": (3, 64, (7, 7), 2, 3, 32, 32, 12, 2, True),
+    "flip 1 channel 3x3 on 16x16": (1, 64, (3, 3), 1, 1, 16, 16, 6, 2, False),
+    "flip 3 channels 5x5 s1 on 24x24 (bands of 10 rows), 40 output channels": (3, 40, (5, 5), 1, 2, 24, 24, 4, 1, True),
+}
+
+
+@pytest.mark.parametrize("name", list(FLIP_STEMS))
+def test_split_flipout_stem_vs_c_oracle(name):
+    """Flipout with <= 3 input channels on the quad flavour (FLIP = true: the sign bits ride in the padding channel of the patch)."""
+    from oracle import c_oracle as CO
+    from bayesian_torch_amd import functional as F
+    Ci, Co, k, st, pd, H, W, B, S, bias = FLIP_STEMS[name]
+    g = torch.Generator().manual_seed(abs(hash(name)) % (1 << 31))
+    mu, rho = torch.randn(Co, Ci, *k, generator=g) * 0.1, torch.randn(Co, Ci, *k, generator=g) * 0.1 - 3
+    mb = torch.randn(Co, generator=g) * 0.1 if bias else None
+    rb = torch.randn(Co, generator=g) * 0.1 - 3 if bias else None
+    x = torch.randn(S * B, Ci, H, W, generator=g)
+    conv = dict(stride=(st, st), padding=(pd, pd), dilation=(1, 1), groups=1)
+    out, _, kn = _run_flip(mu, rho, mb, rb, x, conv, S, 0)
+    assert "fused_split_quad_kernel" in kn and "flip" in kn, kn
+    out32, _, kn32 = _run_flip(mu, rho, mb, rb, x, conv, S, 1)
+    assert "split" not in kn32 and "flip" in kn32, kn32
+    dev = torch.device("cuda")
+    eps_w = F.rng_fill_normal(77, 2, 9, 5, 0, S, mu.shape, dev).cpu()
+    eps_b = F.rng_fill_normal(77, 2, 9, 5, 1, S, (Co,), dev).cpu() if bias else None
+    oshape = tuple(out.shape[1:])
+    s_in = F.rng_fill_sign(77, 2, 9, 5, 2, S, (B, Ci, H, W), dev).cpu()
+    s_out = F.rng_fill_sign(77, 2, 9, 5, 3, S, (B,) + oshape, dev).cpu()
+    out, out32 = out.reshape((S, B) + oshape).cpu(), out32.reshape((S, B) + oshape).cpu()
+    for s in range(S):
+        ref = CO.flipout_fwd(x[s * B:(s + 1) * B], mu, rho, eps_w[s], s_in[s], s_out[s], mb, rb, None if eps_b is None else eps_b[s], conv)
+        assert_close(out[s], ref, RTOL, ATOL, f"{name}[s={s}] split flipout stem vs C oracle")
+        scale = float(ref.abs().max())
+        e_split = float((out[s].double() - ref.double()).abs().max()) / scale
+        e_f32 = float((out32[s].double() - ref.double()).abs().max()) / scale
+        assert e_split <= 4.0 * e_f32 + 1.2e-7, (name, s, e_split, e_f32)
+
+
+def test_split_flipout_stem_fused_maxpool():
+    """Flipout stem -> scale/shift -> ReLU -> MaxPool2d(3, 2, 1) in the quad kernel's output stage == max_pool2d of its unpooled launch."""
+    from bayesian_torch_amd import _lib
+    from bayesian_torch_amd import functional as F
+    g = torch.Generator().manual_seed(6)
+    mu, rho = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).cuda(), (torch.randn(64, 3, 7, 7, generator=g) * 0.1 - 3).cuda()
+    sc, sh = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.3).cuda()
+    x = torch.randn(10, 3, 32, 32, generator=g).cuda()
+    conv = dict(stride=(2, 2), padding=(3, 3), dilation=(1, 1), groups=1)
+    kw = dict(flip=True, conv=conv, S=3, seed=5, call=1, layer_id=4, sample0=0, packed=F.pack_params(mu, rho), post_scale=sc, post_shift=sh, relu=True)
+    pooled = F._fused_forward(x, mu, rho, pool=True, **kw)
+    kn = _lib.lib().bt_last_kernel_name().decode()
+    assert pooled is not None and "fused_split_quad_kernel" in kn and "flip" in kn and "pool=1" in kn, kn
+    full, _ = F.fused_forward(x, mu, rho, **kw)
+    assert "pool=0" in _lib.lib().bt_last_kernel_name().decode()
+    assert tuple(pooled[0].shape) == (30, 64, 8, 8)
+    assert torch.equal(pooled[0], torch.nn.functional.max_pool2d(full, 3, 2, 1))
