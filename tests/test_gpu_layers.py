@@ -334,7 +334,9 @@ def test_fused_maxpool_output_stage(Ci, Co, k, st, pd, H, W, B, flip, fusable):
     pooled_on_split = "split" in _lib.lib().bt_last_kernel_name().decode()      # (stems: the quad flavour pools too)
     assert (direct is not None) == fusable, "fusability of this geometry changed"
     out, _ = F.fused_forward(cu(x), cu(mu), cu(rho), cu(mb), cu(rb), pool=True, **kw)
-    _lib.lib().bt_set_contraction(0 if (pooled_on_split and direct is not None) else 1)       # compare like with like: same contraction flavour as the pooled launch
+    out_on_split = "split" in _lib.lib().bt_last_kernel_name().decode()     # (fused, or the unpooled launch behind a separate pooling pass)
+    assert direct is None or out_on_split == pooled_on_split
+    _lib.lib().bt_set_contraction(0 if out_on_split else 1)       # compare like with like: same contraction flavour as the launch that made `out`
     try:
         full, _ = F.fused_forward(cu(x), cu(mu), cu(rho), cu(mb), cu(rb), **kw)
     finally:
