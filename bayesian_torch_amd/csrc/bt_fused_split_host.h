@@ -1,5 +1,7 @@
 // Host-side helpers shared by the split flavour's translation units (bt_fused_split.hip, bt_fused_split_flip.hip).
 #pragma once
+#include <stdlib.h>
+
 #include "bt_fused_split.h"
 
 namespace bt {
@@ -14,6 +16,11 @@ static inline uint32_t inv_u32(long long d, long long nmax) {
 }
 // Reciprocals of the launch-uniform divisors of the tile decode (every workgroup used to spend ~2,000 cycles dividing).
 static inline void split_fill_inverses(FwdArgs& a) {
+  static const bool off = getenv("BT_NO_HOST_INV") != nullptr;   // test hook: every kernel-side division takes its fallback path
+  if (off) {
+    a.inv_m_tiles = a.inv_S = a.inv_n_tiles = a.inv_n_bt = a.inv_n_ct = a.inv_rw = a.inv_wt = a.inv_kw = 0u;
+    return;
+  }
   const long long tb = a.total_blocks;
   a.inv_m_tiles = inv_u32(a.m_tiles, tb);
   a.inv_S = inv_u32(a.S, tb);

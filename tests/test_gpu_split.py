@@ -424,3 +424,29 @@ def test_split_flipout_stem_fused_maxpool():
     assert "pool=0" in _lib.lib().bt_last_kernel_name().decode()
     assert tuple(pooled[0].shape) == (30, 64, 8, 8)
     assert torch.equal(pooled[0], torch.nn.functional.max_pool2d(full, 3, 2, 1))
+
+
+def test_tile_decode_without_host_reciprocals_is_bit_identical():
+    """FwdArgs::inv_* are an optimisation only: with BT_NO_HOST_INV set (a fresh process: the knob is read once) every kernel
+    divides instead, and a conv layer, a strided one-tap layer, a Flipout layer and a stem give the same bits."""
+    import os, subprocess, sys, hashlib
+    code = r'''
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+from bayesian_torch_amd import functional as F
+def digest(flip, Ci, Co, k, st, pd, H, B, S):
+    g = torch.Generator().manual_seed(Ci * 7 + k)
+    mu = (torch.randn(Co, Ci, k, k, generator=g) * 0.1).cuda(); rho = (torch.randn(Co, Ci, k, k, generator=g) * 0.1 - 3).cuda()
+    x = torch.randn(S * B, Ci, H, H, generator=g).cuda()
+    conv = dict(stride=(st, st), padding=(pd, pd), dilation=(1, 1), groups=1)
+    out, _ = F.fused_forward(x, mu, rho, flip=flip, conv=conv, S=S, shared_x=False, seed=3, call=1, layer_id=2, packed=F.pack_params(mu, rho))
+    return hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()
+print(digest(False, 64, 64, 3, 1, 1, 8, 128, 2), digest(False, 64, 128, 1, 2, 0, 8, 128, 2), digest(True, 64, 64, 3, 1, 1, 8, 128, 2), digest(False, 3, 64, 7, 2, 3, 32, 12, 2))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def run(extra):
+        env = dict(os.environ, **extra)
+        env.pop("BT_NO_HOST_INV", None) if not extra else None
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout.strip().splitlines()[-1]
+    assert run({}) == run({"BT_NO_HOST_INV": "1"})
