@@ -140,7 +140,8 @@ static int launch_split_one(FwdArgs& a, hipStream_t stream) {
     const double eff = (double)a.M / ((double)b.m_tiles * BM);
     if (eff < 0.75) return 1e30;
     const double rounds = (double)((per * b.m_tiles + 255) / 256);
-    return rounds * ((BM > 256 ? BM : 256) + 96);
+    const int synth = BM == 128 ? 128 : 256;   // the producers' floor: the 128-wide tile has 8 producer waves, the others 4
+    return rounds * ((BM > synth ? BM : synth) + 96);
   };
   const double c512 = cost(live512, 512, b512), c256 = cost(live256, 256, b256), c128 = cost(live128, 128, b128);
   int bm = 0;
