@@ -190,8 +190,6 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
   if (n_ach == 1) write_rowtab(0, 0, KC, tid);
 
   const float* const xs = a.x + (long long)s * a.x_sample_stride;
-  const float* const eps_w_s = INJ ? a.eps_w + (long long)s * a.w_elems : nullptr;
-  const float* const sin_s = (FLIP && INJ) ? a.sign_in + (long long)s * a.x_elems : nullptr;
 
   // Buffer resources: 32-bit byte offsets against a scalar base, and the hardware range check returns 0 for an offset
   // past the end -- a masked element is a load at kOOB, no select afterwards. (The host routes tensors of 2^29 elements

@@ -104,9 +104,6 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
   char* const xbuf = smem_c + 2 * W_BYTES;    // [2][X_BYTES]
   float* const smem = reinterpret_cast<float*>(smem_c);
   int4* const taptab = reinterpret_cast<int4*>(smem_c + 2 * (W_BYTES + X_BYTES));
-  double* const red = reinterpret_cast<double*>(smem_c + 2 * (W_BYTES + X_BYTES) + kMaxTaps * 16);
-  int* const misc = reinterpret_cast<int*>(red + 12);
-  (void)red;
 
   unsigned long long* const dbg_ = kStamps ? a.dbg : nullptr;  // stage stamps: diagnostic build only (make STAMPS=1)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

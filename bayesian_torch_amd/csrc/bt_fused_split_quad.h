@@ -33,11 +33,10 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
   constexpr int PBQ = 8 * NP;  // bytes per pixel of the quad patch
   constexpr int W_BYTES = split_w_bytes<BN, NP, FLIP>(), W_OP = W_BYTES / NOP, XQ_BYTES = FLIP ? kQuadXBytesFlip : kQuadXBytes;
   constexpr int W_STEP = 2 * NP * BN * 16, W_HALF = NP * BN * 16, W_PIECE = BN * 16;
-  constexpr int XCAP = XQ_BYTES / PBQ;  // pixels
+  // (the patch region holds XQ_BYTES / PBQ pixels: the host checks PCH against it)
   constexpr int SROWS = BN, SROW = BM + 4;
   static_assert(!FLIP || NP == 3, "Flipout: the exact split");
   static_assert((4 * BN + NOP * SROWS * SROW) * 4 <= 2 * W_BYTES + XQ_BYTES, "output staging fits the operand buffers");
-  constexpr int kMaxChunks = (64 + TPS - 1) / TPS;  // T <= 64
 
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   char* const wbuf = smem_c;                  // [2][W_BYTES]
