@@ -49,6 +49,13 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
   (void)red;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long* const dbg_ = kStamps ? a.dbg : nullptr;  // diagnostic build only (make stamps): tools/stamps.py
+  if (dbg_ && dbg_[201] && tid == 0) {  // per-workgroup timeline
+    dbg_[256 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    dbg_[256 + 4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+  }
+  const bool stamp0 = dbg_ && blockIdx.x == 0 && tid == 0;
+  if (stamp0) dbg_[210] = __builtin_amdgcn_s_memtime();
   const bool producer = wave >= 4;
   const int ptid = producer ? tid - 256 : tid;
   const int li = lane & 31, lh = lane >> 5;
@@ -295,6 +302,7 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
       }
     }
   }
+  if (stamp0) dbg_[212] = __builtin_amdgcn_s_memtime();   // patch staged (this thread's share)
   if (producer) {
     __builtin_amdgcn_s_setprio(3);
     // =================================================== PRODUCERS ===========================================================
@@ -460,7 +468,9 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
           for (int r = 0; r < 16; ++r) acc[o][i][j][r] = 0.f;
 
     __syncthreads();  // patch and stage 0 staged
+    if (stamp0) dbg_[0] = __builtin_amdgcn_s_memtime();
     for (int st = 0; st < NS; ++st) {
+      if (stamp0) dbg_[2 + 2 * st] = __builtin_amdgcn_s_memtime();
       const char* const Wt = wbuf + (st & 1) * W_BYTES;
       const int left = nA - st * TPS, nstep = left >= TPS ? STEPS : (left + 3) >> 2;
       // (step, column group) units in a software pipeline, as in bt_fused_split.h: the stage's tap offsets are fetched first,
@@ -536,10 +546,12 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
           }
         }
       }
+      if (stamp0) dbg_[2 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
       if (kl_block) kl_group();
       __syncthreads();
     }
     if (kl_block) kl_finish();
+    if (stamp0) dbg_[1] = __builtin_amdgcn_s_memtime();
     __syncthreads();  // bias / output-stage constants staged; KL partials published
     if (kl_block && wave == 0) kl_ticket();
 
@@ -580,8 +592,14 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
       combine_flip(tid);
       __syncthreads();
     }
+    if (stamp0) dbg_[121] = __builtin_amdgcn_s_memtime();
     if constexpr (POOL) readout_pool(wave);
     else readout_quads(tid);
+    if (stamp0) dbg_[126] = __builtin_amdgcn_s_memtime();
+  }
+  if (dbg_ && dbg_[201] && tid == 0) {
+    dbg_[256 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    dbg_[256 + 4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime() - dbg_[256 + 4 * blockIdx.x + 2];
   }
 }
 

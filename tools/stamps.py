@@ -57,6 +57,10 @@ if a.wgs:
     percu = collections.Counter((r[4] & 0xf, r[3] & 0xfffffff0) for r in rows)   # (xcc, HW_ID without the wave slot)
     print("distinct (xcc, hw id) slots:", len(percu), " WGs per slot histogram:", collections.Counter(percu.values()))
 t0 = t[0]
+if "quad" in L.bt_last_kernel_name().decode():
+    print("quad kernel (cycles after entry): patch staged %d  loop starts %d  loop ends %d  staged+barrier %d  end %d; stages:" % (
+        t[212] - t[210], t[0] - t[210], t[1] - t[210], t[121] - t[210], t[126] - t[210]), [t[3 + 2 * i] - t[2 + 2 * i] for i in range(3)])
+    sys.exit(0)
 print("prologue (cycles after kernel entry): tap table %d  buffers cleared %d  | producer: units decoded %d  items decoded %d  loads issued %d  stage 0 begins %d | consumer: ready %d  loop starts %d" % (
     t[211] - t[210], t[212] - t[210], t[213] - t[210], t[214] - t[210], t[215] - t[210], t[128] - t[210], t[216] - t[210], t0 - t[210]))
 print("  fast: start->Wloads-issued", t[240]-t[128+6], " Xloads-issued", t[251]-t[240])
