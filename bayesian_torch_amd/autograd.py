@@ -153,11 +153,12 @@ class KLNormal(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, owner_kind, *tensors):
-        owner, kind = owner_kind
+        owner, kind = owner_kind[0], owner_kind[1]
         segs = [tuple(tensors[i:i + 4]) for i in range(0, len(tensors), 4)]
+        lids = list(owner_kind[2]) if len(owner_kind) > 2 else [0] * len(segs)     # (a whole model's segments in ONE launch: get_kl_loss)
         ctx.save_for_backward(*tensors)
         ctx.kind = kind
-        return _lib.kl_normal([tuple(t.detach() for t in sg) for sg in segs], layer_ids=[0] * len(segs), owner=owner, laplace=kind == "laplace")
+        return _lib.kl_normal([tuple(t.detach() for t in sg) for sg in segs], layer_ids=lids, owner=owner, laplace=kind == "laplace")
 
     @staticmethod
     def backward(ctx, g):

@@ -96,10 +96,9 @@ def get_kl_loss(m):
     kl = None
     if segs:
         import torch
-        if torch.is_grad_enabled() and any(t.requires_grad for sg in segs for t in sg):   # training: per-layer differentiable KL
-            for layer in m.modules():
-                if isinstance(layer, FusedBayesLayer):
-                    kl = layer.kl_loss() if kl is None else kl + layer.kl_loss()
+        if torch.is_grad_enabled() and any(t.requires_grad for sg in segs for t in sg):   # training: differentiable, still ONE forward launch
+            from ..autograd import KLNormal
+            kl = KLNormal.apply((("model", id(m)), "normal", tuple(lids)), *[t for sg in segs for t in sg])
         else:
             kl = _lib.kl_normal(segs, layer_ids=lids, owner=("model", id(m)))
     for layer in others:     # foreign modules with a kl_loss of their own
