@@ -164,9 +164,8 @@ class KLNormal(torch.autograd.Function):
     def backward(ctx, g):
         t = ctx.saved_tensors
         grads = [None]
-        if BACKWARD_IMPL == "hip":
-            for i in range(0, len(t), 4):
-                gmu, grho = F.kl_backward(t[i], t[i + 1], t[i + 2], t[i + 3], g, laplace=ctx.kind == "laplace")
+        if BACKWARD_IMPL == "hip":     # every tensor of the call in one launch
+            for gmu, grho in F.kl_backward_segs([tuple(t[i:i + 4]) for i in range(0, len(t), 4)], g, laplace=ctx.kind == "laplace"):
                 grads += [gmu, grho, None, None]
             return tuple(grads)
         for i in range(0, len(t), 4):

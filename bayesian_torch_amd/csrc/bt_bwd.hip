@@ -309,6 +309,44 @@ __global__ __launch_bounds__(256) void kl_normal_bwd_kernel(const float* __restr
 // Workgroups per output tile: first the samples (each group keeps whole samples), then chunks of the reduction axis
 // M = B*Ho*Wo (a training step has ONE sample: layer1's 9 output tiles would otherwise be 9 workgroups on 256 CUs).
 // Chunks are multiples of the LDS stage and at least 8 stages long.
+// All tensors of a model in one launch (get_kl_loss under autograd): block b works on 1024 elements of segment seg(b).
+struct KlBwdSegs {
+  const float *mu[BT_KL_MAX_SEGMENTS], *rho[BT_KL_MAX_SEGMENTS], *pmu[BT_KL_MAX_SEGMENTS], *psig[BT_KL_MAX_SEGMENTS];
+  float *dmu[BT_KL_MAX_SEGMENTS], *drho[BT_KL_MAX_SEGMENTS];
+  long long n[BT_KL_MAX_SEGMENTS];
+  int boff[BT_KL_MAX_SEGMENTS + 1];  // first block of every segment
+  int nseg, laplace;
+};
+__global__ __launch_bounds__(256) void kl_normal_bwd_segs_kernel(const KlBwdSegs a, const float* __restrict__ gup) {
+  int seg = 0;
+  while (seg + 1 < a.nseg && (int)blockIdx.x >= a.boff[seg + 1]) ++seg;   // uniform
+  const long long n = a.n[seg];
+  const float gs = gup[0] / (float)n;
+  const float *mu = a.mu[seg], *rho = a.rho[seg], *pmu = a.pmu[seg], *psig = a.psig[seg];
+  float *dmu = a.dmu[seg], *drho = a.drho[seg];
+  const long long base = (long long)((int)blockIdx.x - a.boff[seg]) * 1024;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + threadIdx.x + 256 * k;
+    if (i < n) {
+      const float m = mu[i], r = rho[i], sq = softplus(r);
+      const float sg = __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __builtin_amdgcn_exp2f(__fmul_rn(-1.4426950408889634f, r))));
+      float gm, gq;
+      if (a.laplace) {
+        const float z = __fmul_rn(m, __builtin_amdgcn_rcpf(__fmul_rn(sq, 1.4142135623730951f)));
+        gm = erff(z);
+        gq = __fsub_rn(__fmul_rn(0.7978845608028654f, __builtin_amdgcn_exp2f(__fmul_rn(-1.4426950408889634f, __fmul_rn(z, z)))), __builtin_amdgcn_rcpf(sq));
+      } else {
+        const float ip = __builtin_amdgcn_rcpf(__fmul_rn(psig[i], psig[i]));
+        gm = __fmul_rn(__fsub_rn(m, pmu[i]), ip);
+        gq = __fsub_rn(__fmul_rn(sq, ip), __builtin_amdgcn_rcpf(sq));
+      }
+      dmu[i] = __fmul_rn(gm, gs);
+      drho[i] = __fmul_rn(__fmul_rn(gq, sg), gs);
+    }
+  }
+}
+
 static int wgrad_groups(const bt_conv2d_geom& g, int S, int* sgroups = nullptr, int* mchunk = nullptr) {
   const int Cig = g.Ci / g.groups, Cog = g.Co / g.groups, Cig4 = (Cig + 3) & ~3, T = g.kh * g.kw;
   const long long tiles = (long long)((T * Cig4 + 63) / 64) * ((Cog + 63) / 64) * g.groups;
@@ -424,4 +462,29 @@ extern "C" int bt_kl_normal_bwd(const float* mu, const float* rho, const float* 
   hipLaunchKernelGGL(kl_normal_bwd_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, (hipStream_t)stream, mu, rho, prior_mu, prior_sigma, grad_kl,
                      (long long)numel, lap, dmu, drho);
   return check_launch("bt_kl_normal_bwd");
+}
+
+extern "C" int bt_kl_normal_bwd_segs(int32_t n_segments, const float* const* mu, const float* const* rho, const float* const* prior_mu,
+                                     const float* const* prior_sigma, const int64_t* numel, const float* grad_kl, uint32_t flags,
+                                     float* const* dmu, float* const* drho, bt_stream_t stream) {
+  using namespace bt;
+  if (n_segments <= 0 || n_segments > BT_KL_MAX_SEGMENTS || !mu || !rho || !numel || !grad_kl || !dmu || !drho)
+    return set_error(BT_ERR_BAD_ARG, "bt_kl_normal_bwd_segs: bad argument");
+  const int lap = (flags & BT_KL_PRIOR_LAPLACE) ? 1 : 0;
+  if (!lap && (!prior_mu || !prior_sigma)) return set_error(BT_ERR_BAD_ARG, "bt_kl_normal_bwd_segs: priors are required for the normal prior");
+  KlBwdSegs a = {};
+  long long blocks = 0;
+  for (int i = 0; i < n_segments; ++i) {
+    if (!mu[i] || !rho[i] || !dmu[i] || !drho[i] || numel[i] <= 0 || (!lap && (!prior_mu[i] || !prior_sigma[i])))
+      return set_error(BT_ERR_BAD_ARG, "bt_kl_normal_bwd_segs: null tensor or empty segment");
+    a.mu[i] = mu[i], a.rho[i] = rho[i], a.pmu[i] = lap ? nullptr : prior_mu[i], a.psig[i] = lap ? nullptr : prior_sigma[i];
+    a.dmu[i] = dmu[i], a.drho[i] = drho[i], a.n[i] = numel[i];
+    a.boff[i] = (int)blocks;
+    blocks += (numel[i] + 1023) / 1024;
+    if (blocks > 0x7FFFFFFFll) return set_error(BT_ERR_UNSUPPORTED, "bt_kl_normal_bwd_segs: too many elements for one launch");
+  }
+  a.boff[n_segments] = (int)blocks;
+  a.nseg = n_segments, a.laplace = lap;
+  hipLaunchKernelGGL(kl_normal_bwd_segs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, grad_kl);
+  return check_launch("bt_kl_normal_bwd_segs");
 }

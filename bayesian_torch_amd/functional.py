@@ -214,3 +214,32 @@ def kl_backward(mu, rho, prior_mu, prior_sigma, grad_kl, laplace=False):
         _lib.check(_lib.lib().bt_kl_normal_bwd(mu.data_ptr(), rho.data_ptr(), _lib.ptr(pm), _lib.ptr(ps), g.data_ptr(), mu.numel(),
                                                _lib.KL_PRIOR_LAPLACE if laplace else 0, dmu.data_ptr(), drho.data_ptr(), _lib.stream_ptr(mu.device)))
     return dmu, drho
+
+
+def kl_backward_segs(segments, grad_kl, laplace=False):
+    """[(d kl / d mu, d kl / d rho) * grad_kl] for every (mu, rho, prior_mu, prior_sigma) segment of bt_kl_normal's sum, ONE HIP
+    launch per BT_KL_MAX_SEGMENTS tensors (bt_kl_normal_bwd_segs): the backward of a whole model's get_kl_loss."""
+    L = _lib.lib()
+    dev = segments[0][0].device
+    g = _lib.dev_f32(grad_kl.reshape(1).contiguous(), "grad_kl")
+    out = []
+    for c0 in range(0, len(segments), _lib.KL_MAX_SEGMENTS):
+        chunk = segments[c0:c0 + _lib.KL_MAX_SEGMENTS]
+        n = len(chunk)
+        arrs = [(C.c_void_p * n)() for _ in range(6)]
+        numel = (C.c_int64 * n)()
+        keep = []
+        for i, (mu, rho, pm, ps) in enumerate(chunk):
+            mu, rho = _lib.dev_f32(mu.detach(), "mu"), _lib.dev_f32(rho.detach(), "rho")
+            pm = None if laplace else _lib.dev_f32(pm, "prior_mu")
+            ps = None if laplace else _lib.dev_f32(ps, "prior_sigma")
+            dmu, drho = torch.empty_like(mu), torch.empty_like(mu)
+            keep.append((mu, rho, pm, ps))
+            out.append((dmu, drho))
+            for a, t in zip(arrs, (mu, rho, pm, ps, dmu, drho)):
+                a[i] = None if t is None else t.data_ptr()
+            numel[i] = mu.numel()
+        with _lib.on(dev):
+            _lib.check(L.bt_kl_normal_bwd_segs(n, arrs[0], arrs[1], arrs[2] if not laplace else None, arrs[3] if not laplace else None, numel, g.data_ptr(),
+                                               _lib.KL_PRIOR_LAPLACE if laplace else 0, arrs[4], arrs[5], _lib.stream_ptr(dev)))
+    return out

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BT_VERSION 200
+#define BT_VERSION 201
 #define BT_WORKSPACE_BYTES 65536
 
 #define BT_OK 0
@@ -212,6 +212,11 @@ int bt_conv2d_bwd(const bt_conv2d_geom *g, int32_t S, int32_t flipout, const flo
  * scalar); flags: BT_KL_PRIOR_LAPLACE for the 'laplace' branch (priors unused then). */
 int bt_kl_normal_bwd(const float *mu, const float *rho, const float *prior_mu, const float *prior_sigma, const float *grad_kl,
                      int64_t numel, uint32_t flags, float *dmu, float *drho, bt_stream_t stream);
+/* The same for up to BT_KL_MAX_SEGMENTS tensors in ONE launch (the backward of a whole model's get_kl_loss): segment arrays are
+ * HOST arrays like bt_kl_normal's; dmu[i] / drho[i] have numel[i] elements. */
+int bt_kl_normal_bwd_segs(int32_t n_segments, const float *const *mu, const float *const *rho, const float *const *prior_mu,
+                          const float *const *prior_sigma, const int64_t *numel, const float *grad_kl, uint32_t flags,
+                          float *const *dmu, float *const *drho, bt_stream_t stream);
 
 /* Contraction arithmetic of the fused forwards (process-wide; default from env BT_CONTRACTION = f32 | bf16x3 | bf16x2):
  *   0  automatic: wherever a launch is eligible, every fp32 operand is cut into three bf16 pieces (an EXACT split of the
