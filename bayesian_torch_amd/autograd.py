@@ -51,7 +51,7 @@ class FusedForward(torch.autograd.Function):
         out, _ = F.fused_forward(x, mu_w, rho_w, mu_b, rho_b, flip=o["flip"], conv=o["conv"], S=o["S"], shared_x=o["shared"],
                                  seed=o["seed"], call=o["call"], layer_id=o["layer_id"], sample0=o["sample0"],
                                  eps_w=o.get("eps_w"), eps_b=o.get("eps_b"), sign_in=o.get("sign_in"), sign_out=o.get("sign_out"),
-                                 packed=o.get("packed"), workspace_owner=("layer", o["layer_id"]))
+                                 packed=o.get("packed"), workspace_owner=("layer", o["layer_id"]), call_base=o.get("call_base"))
         ctx.o = o
         ctx.save_for_backward(x, mu_w, rho_w, mu_b, rho_b)
         ctx.out_shape = tuple(out.shape)
@@ -72,7 +72,7 @@ class FusedForward(torch.autograd.Function):
             packed = o.get("packed") or F.pack_params(mu_w.detach(), rho_w.detach())
             gx, gmu, grho = F.fused_backward(x, g, mu_w.detach(), rho_w, packed, flip=flip, conv=conv, S=S, shared_x=shared, need_x=need_x, need_w=need_w,
                                              eps_w=o.get("eps_w"), sign_in=o.get("sign_in"), sign_out=o.get("sign_out"),
-                                             seed=o["seed"], call=o["call"], layer_id=o["layer_id"], sample0=o["sample0"])
+                                             seed=o["seed"], call=o["call"], layer_id=o["layer_id"], sample0=o["sample0"], call_base=o.get("call_base"))
             gmu_b = grho_b = None
             if mu_b is not None:
                 Co = mu_w.shape[0]
@@ -80,16 +80,18 @@ class FusedForward(torch.autograd.Function):
                 if flip:       # out = mean + (pert + Delta_b) o s_out: mu_b sees g, the bias perturbation sees g o s_out
                     s_out = o.get("sign_out")
                     if s_out is None:
-                        s_out = F.rng_fill_sign(*coords, 3, S, (B,) + tuple(ctx.out_shape[1:]), dev)
+                        s_out = F.rng_fill_sign(*coords, 3, S, (B,) + tuple(ctx.out_shape[1:]), dev, call_base=o.get("call_base"))
                     gp = (g.reshape(s_out.shape) * s_out).reshape((S, B, Co, -1)).sum((1, 3))
                 else:
                     gp = gs.sum((1, 3))
                 eps_b = o.get("eps_b")
                 if eps_b is None:
-                    eps_b = F.rng_fill_normal(*coords, 1, S, (Co,), dev)
+                    eps_b = F.rng_fill_normal(*coords, 1, S, (Co,), dev, call_base=o.get("call_base"))
                 gmu_b = gs.sum((0, 1, 3))
                 grho_b = (gp * eps_b.reshape(S, Co)).sum(0) * torch.sigmoid(rho_b)
             return gx, gmu, grho, gmu_b, grho_b, None
+        if o.get("call_base") is not None:
+            raise RuntimeError("the ATen checker path does not replay graph-captured draws")
         # the draws of the forward, regenerated (or the injected ones)
         eps_w = o.get("eps_w")
         if eps_w is None:

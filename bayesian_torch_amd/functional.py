@@ -170,7 +170,7 @@ def mc_epilogue(logits):
 
 
 def fused_backward(x, grad_out, mu_w, rho_w, packed, *, flip=False, conv=None, S=1, shared_x=True, need_x=True, need_w=True,
-                   eps_w=None, sign_in=None, sign_out=None, seed=0, call=0, layer_id=0, sample0=0):
+                   eps_w=None, sign_in=None, sign_out=None, seed=0, call=0, layer_id=0, sample0=0, call_base=None):
     """Gradients of ``fused_forward`` on the HIP backward kernels (bt_conv2d_bwd): the draws are regenerated on chip from the
     forward's RNG coordinates (or the injected ones are read).  x / grad_out as the forward saw / produced them.
     -> (dx like x or None, dmu_w, drho_w like mu_w or None).  Bias gradients are row sums of grad_out (caller)."""
@@ -193,7 +193,7 @@ def fused_backward(x, grad_out, mu_w, rho_w, packed, *, flip=False, conv=None, S
     ws = torch.empty(max(16, L.bt_conv2d_bwd_workspace(C.byref(geom), S)), dtype=torch.uint8, device=dev)
     inj = [None if t is None else _lib.dev_f32(t, "draw") for t in (eps_w, sign_in, sign_out)]
     P = _lib.bt_params(mu_w.data_ptr(), rho_w.data_ptr(), None, None, None, None, None, None, packed[0].data_ptr(), packed[1].data_ptr(), 0, 0)
-    R = _rng(seed, call, layer_id, sample0, None)
+    R = _rng(seed, call, layer_id, sample0, call_base)     # call_base: the device word of a captured training step (mc.TrainGraph)
     D = _lib.bt_draws(_lib.ptr(inj[0]), None, _lib.ptr(inj[1]), _lib.ptr(inj[2]), R)
     with _lib.on(dev):
         _lib.check(L.bt_conv2d_bwd(C.byref(geom), S, 1 if flip else 0, x.data_ptr(), 0 if shared_x else x_elems, g.data_ptr(), C.byref(P), C.byref(D),

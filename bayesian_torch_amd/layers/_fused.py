@@ -209,9 +209,7 @@ class FusedBayesLayer(BaseVariationalLayer_):
             from ..autograd import FusedForward, KLNormal
             opts = dict(flip=self._flip, conv=conv, S=S, shared=shared, seed=seed, call=call, layer_id=self._layer_id, sample0=sample0,
                         eps_w=draw.get("eps_w"), eps_b=draw.get("eps_b"), sign_in=draw.get("sign_in"), sign_out=draw.get("sign_out"),
-                        packed=self._packed())
-            if call_base is not None:
-                raise RuntimeError("graph-replayed draws (call_base) are not supported on the training path")
+                        packed=self._packed(), call_base=call_base)     # call_base: a captured training step (mc.TrainGraph)
             out = FusedForward.apply(x, mu_t, rho_t, self.mu_bias, self.rho_bias, opts)
             kl = None
             if want_kl:

@@ -109,3 +109,59 @@ class McGraph:
         self.graph.replay()
         rng.set_call(c + self.calls_per_run)
         return self.logits, self.kl, self.packed
+
+
+class TrainGraph:
+    """One TRAINING step -- zero_grad, forward (fused kernels, one MC sample), ``loss_fn(model, out, y)``, backward (HIP dgrad /
+    wgrad with the draws regenerated on chip), optimizer step -- captured once in a HIP graph and replayed per batch: the ~400
+    kernel launches of a ResNet18 step become one graph launch (eager mode is launch-bound).  Fresh draws per step exactly as
+    in McGraph: every forward AND backward kernel adds the device word ``call_base`` to its baked-in call coordinate, so a
+    replay regenerates in its backward the very draws its forward made.  Parameters, gradients and optimizer state live at
+    fixed addresses and are updated in place by the replays; ``loss_fn`` typically is
+    ``lambda m, out, y: cross_entropy(out, y) + get_kl_loss(m) / batch`` (reference loop:
+    examples/main_bayesian_cifar_dnn2bnn.py:402-420)."""
+
+    def __init__(self, model, optimizer, loss_fn, x, y, warmup=3):
+        from . import rng
+        self.x, self.y = x.clone(), y.clone()
+        self.call_base = torch.zeros(1, dtype=torch.int32, device=x.device)
+        B = x.shape[0]
+
+        def run():
+            optimizer.zero_grad(set_to_none=True)
+            with mc_samples(1, B, 0, collect_kl=False, call_base=self.call_base):
+                out = model(self.x)
+            out = out[0] if isinstance(out, tuple) else out
+            loss = loss_fn(model, out, self.y)
+            loss.backward()
+            optimizer.step()
+            return loss.detach()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up outside capture: optimizer state, workspaces, LDS attributes
+            for _ in range(max(2, warmup) - 1):
+                run()
+            c0 = rng.peek_call()
+            run()
+            self.calls_per_run = rng.peek_call() - c0
+        torch.cuda.current_stream().wait_stream(side)
+        self.call0 = rng.peek_call()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = run()
+        rng.set_call(self.call0)               # capture executes nothing: its coordinates are still unused
+
+    def step(self, x=None, y=None):
+        """One optimizer step on (x, y) (default: the captured batch) -> loss (a tensor owned by the graph)."""
+        from . import rng
+        if x is not None:
+            self.x.copy_(x)
+        if y is not None:
+            self.y.copy_(y)
+        c = rng.peek_call()
+        d = (c - self.call0) & 0xFFFFFFFF
+        self.call_base.fill_(d - (1 << 32) if d >= (1 << 31) else d)
+        self.graph.replay()
+        rng.set_call(c + self.calls_per_run)
+        return self.loss

@@ -231,6 +231,10 @@ def train_bench(args, w, dev, world, rank):
         loss.backward()
         opt.step()
         return loss
+    if not args.no_graph:      # the whole step as one HIP graph launch (mc.TrainGraph); --no-graph: ~400 eager launches per step
+        from bayesian_torch_amd.mc import TrainGraph
+        tg = TrainGraph(net, opt, lambda m, out, yy: torch.nn.functional.cross_entropy(out, yy) + get_kl_loss(m) / B, x, y, warmup=max(2, args.warmup))
+        step = tg.step
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -253,7 +257,8 @@ def train_bench(args, w, dev, world, rank):
                               value=round(world * args.steps / dt, 2), unit="MC-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                               ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
                               data="synthetic", config=dict(workload=w["desc"], batch=B, mc_samples_per_step=1, optimizer="SGD momentum 0.9",
-                                                            backward="HIP dgrad/wgrad kernels, draws regenerated on chip", launch="eager"))))
+                                                            backward="HIP dgrad/wgrad kernels, draws regenerated on chip",
+                                                            launch="eager" if args.no_graph else "hip graph replay (mc.TrainGraph)"))))
     if world > 1:
         dist.destroy_process_group()
 

@@ -128,3 +128,44 @@ def test_hip_backward_equals_the_materialising_checker():
     assert grads["hip"].keys() == grads["aten"].keys() and len(grads["hip"]) > 40
     for n in grads["hip"]:
         assert_close(grads["hip"][n].cpu(), grads["aten"][n].cpu(), 2e-4, 2e-5, n)
+
+
+def test_train_graph_replays_the_eager_training_loop():
+    """mc.TrainGraph (one training step in a HIP graph; forward and backward kernels add the device word call_base to their call
+    coordinate) against the same loop run eagerly from the same RNG position: same parameters after the same number of steps,
+    bit for bit -- the replayed backward regenerates the draws of ITS forward, and every kernel sums in a fixed order."""
+    import copy
+    from bayesian_torch_amd import rng
+    from bayesian_torch_amd.harness import resnet as H
+    from bayesian_torch_amd.mc import TrainGraph
+    from bayesian_torch_amd.models.dnn_to_bnn import dnn_to_bnn, get_kl_loss
+    rng.set_mode("philox")
+    torch.manual_seed(0)
+    net = H.resnet18(10, width=8)
+    dnn_to_bnn(net, {"prior_mu": 0.0, "prior_sigma": 1.0, "posterior_mu_init": 0.0, "posterior_rho_init": -3.0,
+                     "type": "Reparameterization", "moped_enable": False, "moped_delta": 0.5})
+    net = net.cuda().train()
+    ref = copy.deepcopy(net)
+    x = torch.randn(16, 3, 32, 32).cuda()
+    y = torch.randint(0, 10, (16,)).cuda()
+    loss_fn = lambda m, out, yy: torch.nn.functional.cross_entropy(out, yy) + get_kl_loss(m) / 16
+    n_warm, n_steps = 3, 4
+
+    rng.manual_seed(11)
+    opt_r = torch.optim.SGD(ref.parameters(), lr=0.01, momentum=0.9)
+    eager_losses = []
+    for _ in range(n_warm + n_steps):
+        opt_r.zero_grad(set_to_none=True)
+        loss = loss_fn(ref, ref(x), y)
+        loss.backward()
+        opt_r.step()
+        eager_losses.append(float(loss))
+
+    rng.manual_seed(11)
+    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
+    tg = TrainGraph(net, opt, loss_fn, x, y, warmup=n_warm)        # n_warm real steps, eager
+    graph_losses = [float(tg.step()) for _ in range(n_steps)]
+    assert graph_losses == eager_losses[n_warm:], (graph_losses, eager_losses)
+    for (k, a), (_, b) in zip(net.state_dict().items(), ref.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert len(set(graph_losses)) == n_steps       # fresh draws every replay
