@@ -208,3 +208,28 @@ extern "C" int bt_pack_params(const float* mu_w, const float* rho_w, int64_t Co,
                      mu_packed, sigma_packed);
   return check_launch("bt_pack_params");
 }
+
+// Test hook (not part of include/bt_hip.h): fills the whole LDS of every CU with NaN patterns (fp32 quiet NaNs = bf16 NaN pairs).
+// LDS is not cleared between kernels, so a kernel that reads an LDS slot it never wrote sees them: tests/test_gpu_split.py runs
+// the split kernels behind this and expects finite, unchanged results.
+namespace bt {
+__global__ __launch_bounds__(1024) void poison_lds_kernel(unsigned* sink) {
+  extern __shared__ unsigned lds[];
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 1024) lds[i] = 0x7FC07FC0u;
+  __syncthreads();
+  if (lds[(threadIdx.x * 37) % (160 * 1024 / 4)] == 1u) sink[0] = 1u;   // (keeps the stores alive)
+}
+}  // namespace bt
+extern "C" int bt_debug_poison_lds(void* scratch_word, bt_stream_t stream) {
+  using namespace bt;
+  static bool flags[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return set_error(BT_ERR_HIP_BASE, "bt_debug_poison_lds: hipGetDevice failed");
+  if (!flags[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return set_error(BT_ERR_HIP_BASE, "bt_debug_poison_lds: cannot raise the dynamic LDS limit");
+    flags[dev] = true;
+  }
+  hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(1024), 160 * 1024, (hipStream_t)stream, (unsigned*)scratch_word);
+  return check_launch("bt_debug_poison_lds");
+}

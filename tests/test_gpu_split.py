@@ -450,3 +450,55 @@ print(digest(False, 64, 64, 3, 1, 1, 8, 128, 2), digest(False, 64, 128, 1, 2, 0,
         assert r.returncode == 0, r.stderr[-2000:]
         return r.stdout.strip().splitlines()[-1]
     assert run({}) == run({"BT_NO_HOST_INV": "1"})
+
+
+POISON_CASES = ["layer1 64x64 3x3 8x8 (512 tile, 9 taps)", "odd octet count, one tap", "9 octets, partial channel tile, bias",
+                "downsample 64->128 1x1 s2 (one tap: octet pairs)", "1x1 maps, partial batch tile (B = 120)", "groups 2, 3x2 kernel, stride (2,1)",
+                "layer3 256x256 3x3 on 2x2 maps (pixel-major, 4 of 9 taps, xm=2)", "14x14 maps 3x3 (W % 4 != 0: whole planes fetched flat)",
+                "28x28 -> 14x14 1x1 s2 (every second column, XM 4)", "row bands 64x64 3x3 56x56"]
+
+
+def test_split_kernels_never_read_lds_they_did_not_write():
+    """The split kernels clear only their weight buffers and the shared zero pixels (bt_fused_split.h), the stem kernels nothing:
+    every other LDS slot a consumer reads must have been written by a producer of the same workgroup. LDS survives from kernel
+    to kernel, so fill all of it with NaN patterns (test hook bt_debug_poison_lds) right before each launch: Reparameterization,
+    Flipout and stem launches over ragged geometries stay finite and bit-identical to the unpoisoned launch."""
+    import ctypes
+    from bayesian_torch_amd import _lib
+    L = _lib.lib()
+    L.bt_debug_poison_lds.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.bt_debug_poison_lds.restype = ctypes.c_int
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def poison():
+        assert L.bt_debug_poison_lds(word.data_ptr(), _lib.stream_ptr(word.device)) == 0
+
+    for name in POISON_CASES:
+        mu, rho, mb, rb, x, conv, B, S = _case(name)
+        clean, kn = _run(mu, rho, mb, rb, x, conv, S, 0)
+        poison()
+        dirty, _ = _run(mu, rho, mb, rb, x, conv, S, 0)
+        assert "split" in kn and torch.isfinite(dirty).all() and torch.equal(clean, dirty), (name, kn)
+    for name in ("flip layer1 64x64 3x3 8x8 (row pieces, xm=3)", "flip W % 4 != 0 (generic fetch) 24x64 3x3 6x6",
+                 "flip layer4 512x512 3x3 on 1x1 maps (128 tile, one tap, xm=1)", "flip small batch 64x64 3x3 4x4, B = 16 (128 tile of whole images)"):
+        mu, rho, mb, rb, x, conv, B, S = _flip_case(name)
+        clean, _, kn = _run_flip(mu, rho, mb, rb, x, conv, S, 0)
+        poison()
+        dirty, _, _ = _run_flip(mu, rho, mb, rb, x, conv, S, 0)
+        assert "split" in kn and torch.isfinite(dirty).all() and torch.equal(clean, dirty), (name, kn)
+    for name in ("9 octets, partial channel tile, bias", "odd octet count, one tap", "dilation 2", "layer2.0 64->128 3x3 s2"):   # the fp32-MFMA kernels too
+        mu, rho, mb, rb, x, conv, B, S = _case(name)
+        clean, kn = _run(mu, rho, mb, rb, x, conv, S, 1)
+        poison()
+        dirty, _ = _run(mu, rho, mb, rb, x, conv, S, 1)
+        assert "split" not in kn and torch.isfinite(dirty).all() and torch.equal(clean, dirty), (name, kn)
+    for flip in (False, True):     # stems (quad kernels: no clear at all), ragged channel count
+        g = torch.Generator().manual_seed(9)
+        mu, rho = torch.randn(40, 3, 7, 7, generator=g) * 0.1, torch.randn(40, 3, 7, 7, generator=g) * 0.1 - 3
+        x = torch.randn(2 * 5, 3, 32, 32, generator=g)
+        conv = dict(stride=(2, 2), padding=(3, 3), dilation=(1, 1), groups=1)
+        clean = (_run_flip(mu, rho, None, None, x, conv, 2, 0) if flip else _run(mu, rho, None, None, x, conv, 2, 0))[0]
+        assert "fused_split_quad_kernel" in L.bt_last_kernel_name().decode()
+        poison()
+        dirty = (_run_flip(mu, rho, None, None, x, conv, 2, 0) if flip else _run(mu, rho, None, None, x, conv, 2, 0))[0]
+        assert torch.isfinite(dirty).all() and torch.equal(clean, dirty), ("stem", flip)
