@@ -160,6 +160,7 @@ static int launch_split_one(FwdArgs& a, hipStream_t stream) {
   if (xal && a.HW == 1) xm = 1;
   else if (xal && bm != 128 && !a.pixel_major && a.HW > 1 && (a.W & 3) == 0 && a.t_Wt == a.Wo && split_row_mode(a)) xm = split_row_mode(a);
   else if (xal && bm != 128 && !a.pixel_major && a.HW > 1 && split_plane_flat(a)) xm = 3, a.x_flat = 1;
+  else if (xal && bm == 128 && !a.pixel_major && a.H == 2 && a.W == 2 && split_plane_flat(a)) xm = 2;   // whole 2x2 planes (a strided 3x3 down to 1x1 maps)
   else if (xal && a.pixel_major && a.H == 2 && a.W == 2 && a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.SH == 1 && a.SW == 1 && a.DH == 1 && a.DW == 1) xm = 2;
   if (bm == 512) return launch_split_xm<512, 4>(a, mode, xm, stream);
   if (bm == 256) return launch_split_xm<256, 4>(a, mode, xm, stream);
