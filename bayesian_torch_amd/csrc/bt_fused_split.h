@@ -314,6 +314,9 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     uint32_t e_off[UMAX];  // draw index (== element offset in the packed tensors) of the unit at octet 0 of stage 0
     int l_off[UMAX];       // LDS byte offset inside a W buffer; -1: no slot
     int u_ol[UMAX];        // octet inside the stage
+    bool u_live[UMAX];     // wave-uniform: some lane of this wave holds a row that exists. A wave whose rows all lie past Cog (the
+                           // classifier head: 10 of 64 rows) skips the unit -- loads, draws, split, LDS writes; its W slots keep
+                           // the zeros of the initial clear.
     const uint32_t inv_na = nA > 1 ? inv32(nA) : 0u;
 #pragma unroll
     for (int i = 0; i < UMAX; ++i) {
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       //  consecutive lanes when one tap is active -- then write different banks; reads stay 16 distinct slots per lane group)
       l_off[i] = u < nunits ? st_ * W_STEP + hf * W_HALF + (n ^ ((2 * st_ + hf) & 7)) * 16 + cq * 8 : -1;
       u_ol[i] = ol;
+      u_live[i] = __ballot(rv && u < nunits) != 0ull;
     }
     const int wave_u0 = __builtin_amdgcn_readfirstlane(ptid & ~63);
     if (stamp0) dbg_[213] = __builtin_amdgcn_s_memtime();
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       const int oct0 = st * NO;
 #pragma unroll
       for (int i = 0; i < UMAX; ++i) {
-        if (i == 0 || wave_u0 + kProducers * i < nunits) {  // wave-uniform
+        if (u_live[i]) {  // wave-uniform
           const bool in = l_off[i] >= 0 && oct0 + u_ol[i] < G8 && e_off[i] != (kOOB >> 2);
           const uint32_t sb = in ? 4u * (e_off[i] + (uint32_t)(8 * oct0)) : kOOB;
           mu[i] = ldf4(r_mu, sb), rs[i] = ldf4(r_rs, sb);
@@ -557,13 +561,13 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         float ep[UMAX][4];
 #pragma unroll
         for (int i = 0; i < UMAX; ++i)
-          if (i == 0 || wave_u0 + kProducers * i < nunits)  // wave-uniform
+          if (u_live[i])  // wave-uniform
             philox_normal4(key_w, sample, (e_off[i] + (uint32_t)(8 * oct0)) >> 2, ep[i]);
         if (pstamp && st == 3) dbg_[252] = __builtin_amdgcn_s_memtime();
         // ---- sampled weights -> pieces -> LDS ----
 #pragma unroll
         for (int i = 0; i < UMAX; ++i) {
-          if (i == 0 || wave_u0 + kProducers * i < nunits) {  // wave-uniform
+          if (u_live[i]) {  // wave-uniform
             const float m4[4] = {mu[i].x, mu[i].y, mu[i].z, mu[i].w}, s4[4] = {rs[i].x, rs[i].y, rs[i].z, rs[i].w};
             uint32_t wh[4], wm_[4], wl[4];
 #pragma unroll
