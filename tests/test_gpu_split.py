@@ -502,3 +502,68 @@ def test_split_kernels_never_read_lds_they_did_not_write():
         poison()
         dirty = (_run_flip(mu, rho, None, None, x, conv, 2, 0) if flip else _run(mu, rho, None, None, x, conv, 2, 0))[0]
         assert torch.isfinite(dirty).all() and torch.equal(clean, dirty), ("stem", flip)
+
+
+def _rand_geometry(r):
+    """A random conv geometry the split flavour may or may not take (channels in octets or <= 4, <= 9 taps)."""
+    stem = r.random() < 0.2
+    groups = 1 if stem else r.choice([1, 1, 1, 2])
+    Cig = r.choice([1, 2, 3, 4]) if stem else 8 * r.randint(1, 9)
+    Co = groups * r.choice([8, 10, 24, 40, 64, 72, 96, 130])
+    kh, kw = (r.choice([3, 5, 7]),) * 2 if stem else (r.randint(1, 3), r.randint(1, 3))
+    st = (r.choice([1, 1, 2]), r.choice([1, 1, 2]))
+    dl = (1, 1) if stem else (r.choice([1, 1, 2]), r.choice([1, 1, 2]))
+    pd = (r.randint(0, (kh - 1) * dl[0]), r.randint(0, (kw - 1) * dl[1]))
+    H, W = r.choice([1, 2, 3, 4, 6, 7, 8, 12, 14, 16, 20, 28]), r.choice([1, 2, 3, 4, 6, 7, 8, 12, 14, 16, 20, 28])
+    if H + 2 * pd[0] < (kh - 1) * dl[0] + 1 or W + 2 * pd[1] < (kw - 1) * dl[1] + 1:
+        H, W = max(H, kh * dl[0]), max(W, kw * dl[1])
+    B = r.choice([1, 3, 8, 16, 33, 64, 128])
+    while B * H * W * Cig * groups > 1 << 21:
+        B = max(1, B // 2)
+    return dict(Ci=Cig * groups, Co=Co, k=(kh, kw), st=st, pd=pd, dl=dl, groups=groups, H=H, W=W, B=B, S=r.choice([1, 2, 5]),
+                bias=r.random() < 0.5, flip=r.random() < 0.4)
+
+
+def test_random_geometries_split_agrees_with_the_fp32_kernels():
+    """120 random geometries (strides, dilations, groups, ragged channel counts, 1..28-pixel maps, stems, Flipout), each launched
+    in automatic mode (split wherever eligible) behind NaN-poisoned LDS and in fp32 mode: finite and equal within the
+    contraction's rounding. The fp32 kernels are held to the oracle elsewhere; this sweeps the tile / fetch-mode selection."""
+    import ctypes, random
+    from bayesian_torch_amd import _lib
+    from bayesian_torch_amd import functional as F
+    L = _lib.lib()
+    L.bt_debug_poison_lds.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.bt_debug_poison_lds.restype = ctypes.c_int
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    r = random.Random(20261004)
+    taken = {}
+    import os
+    ncases = int(os.environ.get("BT_FUZZ_CASES", "120"))     # (a one-off sweep of 2000 cases was clean in round 2)
+    for case in range(ncases):
+        g = _rand_geometry(r)
+        gen = torch.Generator().manual_seed(case)
+        wshape = (g["Co"], g["Ci"] // g["groups"]) + g["k"]
+        mu, rho = (torch.randn(wshape, generator=gen) * 0.1).cuda(), (torch.randn(wshape, generator=gen) * 0.1 - 3).cuda()
+        mb = (torch.randn(g["Co"], generator=gen) * 0.1).cuda() if g["bias"] else None
+        rb = (torch.randn(g["Co"], generator=gen) * 0.1 - 3).cuda() if g["bias"] else None
+        x = torch.randn(g["S"] * g["B"], g["Ci"], g["H"], g["W"], generator=gen).cuda()
+        conv = dict(stride=g["st"], padding=g["pd"], dilation=g["dl"], groups=g["groups"])
+        kw = dict(flip=g["flip"], conv=conv, S=g["S"], shared_x=False, seed=5, call=case, layer_id=3, packed=F.pack_params(mu, rho))
+        outs = {}
+        for mode in (0, 1):
+            _lib.check(L.bt_set_contraction(mode))
+            try:
+                assert L.bt_debug_poison_lds(word.data_ptr(), _lib.stream_ptr(word.device)) == 0
+                outs[mode], _ = F.fused_forward(x, mu, rho, mb, rb, **kw)
+                if mode == 0:
+                    kn = L.bt_last_kernel_name().decode()
+                    taken[kn.split("<")[0] + ("/flip" if g["flip"] else "")] = taken.get(kn.split("<")[0] + ("/flip" if g["flip"] else ""), 0) + 1
+            finally:
+                L.bt_set_contraction(0)
+        a, b = outs[0], outs[1]
+        assert torch.isfinite(a).all() and torch.isfinite(b).all(), (case, g, kn)
+        scale = float(b.abs().max()) + 1e-30
+        err = float((a - b).abs().max()) / scale
+        assert err < 2e-5, (case, g, kn, err)
+    print("kernels taken in automatic mode:", taken)
+    assert sum(v for k, v in taken.items() if "split" in k) >= ncases // 3, taken
