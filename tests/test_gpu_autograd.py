@@ -169,3 +169,50 @@ def test_train_graph_replays_the_eager_training_loop():
     for (k, a), (_, b) in zip(net.state_dict().items(), ref.state_dict().items()):
         assert torch.equal(a, b), k
     assert len(set(graph_losses)) == n_steps       # fresh draws every replay
+
+
+def test_random_geometries_hip_backward_equals_the_checker():
+    """40 random conv layers (strides, dilations, groups, stems, Flipout, S in {1, 2, 3}): dx, dmu, drho of the HIP dgrad / wgrad
+    kernels -- tap skipping, output-channel pieces, reduction-axis chunks -- against the materialising ATen path on the same draws."""
+    import random
+    import bayesian_torch_amd.autograd as AG
+    import bayesian_torch_amd.layers as L
+    from bayesian_torch_amd import mc, rng
+    rng.set_mode("philox")
+    r = random.Random(7)
+    for case in range(40):
+        flip = r.random() < 0.4
+        groups = r.choice([1, 1, 2])
+        Ci = groups * r.choice([1, 3, 4, 8, 16, 24, 40, 64])
+        Co = groups * r.choice([4, 8, 20, 32, 64, 96])
+        kh, kw = r.randint(1, 3), r.randint(1, 3)
+        st, dl = (r.choice([1, 1, 2]), r.choice([1, 1, 2])), (r.choice([1, 1, 2]), r.choice([1, 1, 2]))
+        pd = (r.randint(0, (kh - 1) * dl[0]), r.randint(0, (kw - 1) * dl[1]))
+        H, W = r.choice([1, 2, 4, 5, 8, 12, 16]), r.choice([1, 2, 4, 5, 8, 12, 16])
+        H, W = max(H, (kh - 1) * dl[0] + 1 - 2 * pd[0], 1), max(W, (kw - 1) * dl[1] + 1 - 2 * pd[1], 1)
+        B, S = r.choice([1, 2, 5, 16, 48]), r.choice([1, 2, 3])
+        cls = L.Conv2dFlipout if flip else L.Conv2dReparameterization
+        kwargs = dict(in_channels=Ci, out_channels=Co, kernel_size=(kh, kw), stride=st, padding=pd, dilation=dl, groups=groups, bias=r.random() < 0.5)
+        if not flip:
+            kwargs["prior_type"] = "normal"
+        torch.manual_seed(case)
+        layer = cls(**kwargs).cuda()
+        x0 = torch.randn(B, Ci, H, W).cuda()
+        grads = {}
+        for impl in ("hip", "aten"):
+            AG.BACKWARD_IMPL = impl
+            try:
+                rng.manual_seed(100 + case)
+                layer.zero_grad()
+                x = x0.clone().requires_grad_(True)
+                with mc.mc_samples(S, B):
+                    out, kl = layer(x)
+                gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(case)).cuda()
+                ((out * gout).sum() + 2.0 * kl).backward()
+                grads[impl] = [x.grad.clone()] + [p.grad.clone() for p in layer.parameters() if p.grad is not None]
+            finally:
+                AG.BACKWARD_IMPL = "hip"
+        assert len(grads["hip"]) == len(grads["aten"]) >= 3
+        for i, (a, b) in enumerate(zip(grads["hip"], grads["aten"])):
+            assert torch.isfinite(a).all(), (case, kwargs, i)
+            assert_close(a.cpu(), b.cpu(), 2e-4, 2e-5, f"case {case} {kwargs} H{H} W{W} B{B} S{S} grad {i}")
