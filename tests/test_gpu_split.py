@@ -541,13 +541,16 @@ def test_random_geometries_split_agrees_with_the_fp32_kernels():
     ncases = int(os.environ.get("BT_FUZZ_CASES", "120"))     # (a one-off sweep of 2000 cases was clean in round 2)
     for case in range(ncases):
         g = _rand_geometry(r)
+        linear = r.random() < 0.15       # Linear layers: [B, In] inputs, the fused kernels' 1x1 geometry
+        if linear:
+            g.update(Ci=r.choice([8, 40, 64, 100, 512, 784, 1000]), groups=1, k=(), H=1, W=1, B=r.choice([1, 7, 64, 128, 256]))
         gen = torch.Generator().manual_seed(case)
         wshape = (g["Co"], g["Ci"] // g["groups"]) + g["k"]
         mu, rho = (torch.randn(wshape, generator=gen) * 0.1).cuda(), (torch.randn(wshape, generator=gen) * 0.1 - 3).cuda()
         mb = (torch.randn(g["Co"], generator=gen) * 0.1).cuda() if g["bias"] else None
         rb = (torch.randn(g["Co"], generator=gen) * 0.1 - 3).cuda() if g["bias"] else None
-        x = torch.randn(g["S"] * g["B"], g["Ci"], g["H"], g["W"], generator=gen).cuda()
-        conv = dict(stride=g["st"], padding=g["pd"], dilation=g["dl"], groups=g["groups"])
+        x = (torch.randn(g["S"] * g["B"], g["Ci"], generator=gen) if linear else torch.randn(g["S"] * g["B"], g["Ci"], g["H"], g["W"], generator=gen)).cuda()
+        conv = None if linear else dict(stride=g["st"], padding=g["pd"], dilation=g["dl"], groups=g["groups"])
         kw = dict(flip=g["flip"], conv=conv, S=g["S"], shared_x=False, seed=5, call=case, layer_id=3, packed=F.pack_params(mu, rho))
         outs = {}
         for mode in (0, 1):
