@@ -504,7 +504,7 @@ def test_split_kernels_never_read_lds_they_did_not_write():
         assert torch.isfinite(dirty).all() and torch.equal(clean, dirty), ("stem", flip)
 
 
-def _rand_geometry(r):
+def _rand_geometry(r, big=False):
     """A random conv geometry the split flavour may or may not take (channels in octets or <= 4, <= 9 taps)."""
     stem = r.random() < 0.2
     groups = 1 if stem else r.choice([1, 1, 1, 2])
@@ -518,9 +518,17 @@ def _rand_geometry(r):
     if H + 2 * pd[0] < (kh - 1) * dl[0] + 1 or W + 2 * pd[1] < (kw - 1) * dl[1] + 1:
         H, W = max(H, kh * dl[0]), max(W, kw * dl[1])
     B = r.choice([1, 3, 8, 16, 33, 64, 128])
-    while B * H * W * Cig * groups > 1 << 21:
-        B = max(1, B // 2)
-    return dict(Ci=Cig * groups, Co=Co, k=(kh, kw), st=st, pd=pd, dl=dl, groups=groups, H=H, W=W, B=B, S=r.choice([1, 2, 5]),
+    S = r.choice([1, 2, 5])
+    if big:      # chip-filling launches: the wide tiles (64 x 512 / 64 x 256) are only chosen when there are rounds of workgroups to save
+        B, S = r.choice([64, 100, 128]), r.choice([8, 16, 32])
+        if not stem:
+            Cig = 8 * r.randint(1, 8)
+        while S * B * H * W * Cig * groups > 1 << 25:
+            S = max(1, S // 2)
+    else:
+        while B * H * W * Cig * groups > 1 << 21:
+            B = max(1, B // 2)
+    return dict(Ci=Cig * groups, Co=Co, k=(kh, kw), st=st, pd=pd, dl=dl, groups=groups, H=H, W=W, B=B, S=S,
                 bias=r.random() < 0.5, flip=r.random() < 0.4)
 
 
@@ -540,7 +548,7 @@ def test_random_geometries_split_agrees_with_the_fp32_kernels():
     import os
     ncases = int(os.environ.get("BT_FUZZ_CASES", "120"))     # (a one-off sweep of 2000 cases was clean in round 2)
     for case in range(ncases):
-        g = _rand_geometry(r)
+        g = _rand_geometry(r, big=case % 4 == 3)
         linear = r.random() < 0.15       # Linear layers: [B, In] inputs, the fused kernels' 1x1 geometry
         if linear:
             g.update(Ci=r.choice([8, 40, 64, 100, 512, 784, 1000]), groups=1, k=(), H=1, W=1, B=r.choice([1, 7, 64, 128, 256]))
@@ -560,7 +568,8 @@ def test_random_geometries_split_agrees_with_the_fp32_kernels():
                 outs[mode], _ = F.fused_forward(x, mu, rho, mb, rb, **kw)
                 if mode == 0:
                     kn = L.bt_last_kernel_name().decode()
-                    taken[kn.split("<")[0] + ("/flip" if g["flip"] else "")] = taken.get(kn.split("<")[0] + ("/flip" if g["flip"] else ""), 0) + 1
+                    key = kn.split("<")[0] + ("/" + kn.split(",")[1] if "split_kernel" in kn else "") + ("/flip" if g["flip"] else "")   # kernel / tile width
+                    taken[key] = taken.get(key, 0) + 1
             finally:
                 L.bt_set_contraction(0)
         a, b = outs[0], outs[1]
