@@ -573,6 +573,20 @@ def test_random_geometries_split_agrees_with_the_fp32_kernels():
             finally:
                 L.bt_set_contraction(0)
         a, b = outs[0], outs[1]
+        if case % 3 == 0 and x.numel() <= 300000 and not linear:     # and sample 0 against the plain-C oracle on the replayed draws
+            from oracle import c_oracle as CO
+            dev = torch.device("cuda")
+            Bq, S_ = g["B"], g["S"]
+            eps_w = F.rng_fill_normal(5, case, 3, 0, 0, S_, mu.shape, dev).cpu()
+            eps_b = F.rng_fill_normal(5, case, 3, 0, 1, S_, (g["Co"],), dev).cpu() if g["bias"] else None
+            xs, cm = x[:Bq].cpu(), lambda t: None if t is None else t.cpu()
+            if g["flip"]:
+                s_in = F.rng_fill_sign(5, case, 3, 0, 2, S_, (Bq,) + tuple(x.shape[1:]), dev).cpu()
+                s_out = F.rng_fill_sign(5, case, 3, 0, 3, S_, (Bq,) + tuple(a.shape[1:]), dev).cpu()
+                ref = CO.flipout_fwd(xs, mu.cpu(), rho.cpu(), eps_w[0], s_in[0], s_out[0], cm(mb), cm(rb), None if eps_b is None else eps_b[0], conv)
+            else:
+                ref = CO.reparam_fwd(xs, mu.cpu(), rho.cpu(), eps_w[0], cm(mb), cm(rb), None if eps_b is None else eps_b[0], conv)
+            assert_close(a[:Bq].cpu(), ref, RTOL, ATOL, f"fuzz case {case} {g} {kn} vs C oracle")
         assert torch.isfinite(a).all() and torch.isfinite(b).all(), (case, g, kn)
         scale = float(b.abs().max()) + 1e-30
         err = float((a - b).abs().max()) / scale
