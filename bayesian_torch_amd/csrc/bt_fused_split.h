@@ -176,6 +176,9 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         const int lo_h = a.PH - e.y, lo_w = a.PW - e.z;
         const int hc = lo_h > 0 ? div_small(lo_h + a.SH - 1, a.SH) : 0, wc = lo_w > 0 ? div_small(lo_w + a.SW - 1, a.SW) : 0;
         act = hc < a.Ho && hc * a.SH - lo_h < a.H && wc < a.Wo && wc * a.SW - lo_w < a.W;
+        if (a.row_taps) {  // tiles of ONE output row (images x row r0): only the kernel rows that meet data for THIS row
+          act = act && (unsigned)(r0 * a.SH - a.PH + e.y) < (unsigned)a.H;
+        }
       }
     }
     const unsigned long long mask = __ballot(act);

@@ -51,6 +51,9 @@ static int launch_split_xm(FwdArgs& a, int mode, int xm, hipStream_t stream) {
   } else {
     if (xm == 3) return launch_split_cfg<BM, 3, NPW, 3>(a, stream);
     if (xm == 4) return launch_split_cfg<BM, 3, NPW, 4>(a, stream);
+    if constexpr (BM == 256) {
+      if (xm == 2) return launch_split_cfg<BM, 3, NPW, 2>(a, stream);
+    }
   }
   return launch_split_cfg<BM, 3, NPW, 0>(a, stream);
 }
@@ -161,6 +164,7 @@ static int launch_split_one(FwdArgs& a, hipStream_t stream) {
   else if (xal && bm != 128 && !a.pixel_major && a.HW > 1 && (a.W & 3) == 0 && a.t_Wt == a.Wo && split_row_mode(a)) xm = split_row_mode(a);
   else if (xal && bm != 128 && !a.pixel_major && a.HW > 1 && split_plane_flat(a)) xm = 3, a.x_flat = 1;
   else if (xal && bm == 128 && !a.pixel_major && a.H == 2 && a.W == 2 && split_plane_flat(a)) xm = 2;   // whole 2x2 planes (a strided 3x3 down to 1x1 maps)
+  else if (xal && bm != 512 && a.row_taps && a.H == 2 && a.W == 2 && a.KW == 3 && a.PW == 1 && a.SW == 1 && a.DW == 1) xm = 2;   // a row tile's patch is the whole 2x2 plane
   else if (xal && a.pixel_major && a.H == 2 && a.W == 2 && a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.SH == 1 && a.SW == 1 && a.DH == 1 && a.DW == 1) xm = 2;
   if (bm == 512) return launch_split_xm<512, 4>(a, mode, xm, stream);
   if (bm == 256) return launch_split_xm<256, 4>(a, mode, xm, stream);
@@ -172,6 +176,16 @@ static int launch_split_one(FwdArgs& a, hipStream_t stream) {
 // tap once for all pixels -- usually do, and beat the fp32 kernels (165 -> 104 us on ResNet18's layer3.0.conv1).
 int launch_split(FwdArgs& a, hipStream_t stream) {
   FwdArgs t = a;
+  // Two-row maps with a stride-1 window (ResNet18 / CIFAR layer3: 3x3 on 2x2): tiles of (images x ONE output row) before the
+  // pixel-major ones. A row's pixels share 6 of the 9 taps: 3 MFMA steps and 6 weight draws per octet for 2 pixels instead of
+  // 2 x (2 steps, 4 draws), and half the workgroups. The choice is geometric (never a matter of S or of the tile width), so
+  // the tap pairing -- the K order -- of a layer stays the same for every launch split.
+  if (a.pixel_major && a.Ho == 2 && a.Wo >= 2 && a.SH == 1 && a.KH == 3 && a.PH == 1 && a.DH == 1 && !a.ep_pool) {
+    t.pixel_major = 0, t.out_vec4 = 0, t.row_taps = 1;
+    const int rcr = launch_split_one(t, stream);
+    if (rcr <= 0) { a = t; return rcr; }
+    t = a;
+  }
   int rc = launch_split_one(t, stream);
   if (rc == 1 && a.pixel_major) {
     t = a;

@@ -100,7 +100,7 @@ static bool split_plane_flat(const FwdArgs& a) {
 template <int BM, bool FLIP = false>
 static int split_geometry(FwdArgs& a) {
   int nh, nw, dys, dxs, nh_min = 0, nw_min = 0;
-  tap_window(a.KH, a.DH, a.SH, a.PH, a.H, a.Ho, a.pixel_major != 0, &nh, &dys, &nh_min);
+  tap_window(a.KH, a.DH, a.SH, a.PH, a.H, a.Ho, a.pixel_major != 0 || a.row_taps != 0, &nh, &dys, &nh_min);   // (row tiles: the window of ONE output row)
   tap_window(a.KW, a.DW, a.SW, a.PW, a.W, a.Wo, a.pixel_major != 0, &nw, &dxs, &nw_min);
   // One active tap: the canonical K order pairs consecutive octets in one MFMA step, so a stage has to hold TWO octet planes
   // whatever the tile (otherwise the pairing, and with it the rounding, would depend on the tile choice). Pixel-major tiles
@@ -116,7 +116,11 @@ static int split_geometry(FwdArgs& a) {
     return NI * PHt * PWt <= XPO;
   };
   int NI, R, Wt;
-  if (a.HoWo == 1 || a.pixel_major) {
+  if (a.row_taps) {   // images x one output row (bt_fused_split.hip: 2-row maps)
+    NI = BM / a.Wo, R = 1, Wt = a.Wo;
+    if (NI > a.B) NI = a.B;
+    if (NI < 1 || !fits(NI, R, Wt)) return 0;
+  } else if (a.HoWo == 1 || a.pixel_major) {
     NI = BM, R = 1, Wt = 1;
     if (NI > a.B) NI = a.B;
     if (!fits(NI, R, Wt)) return 0;
@@ -135,7 +139,7 @@ static int split_geometry(FwdArgs& a) {
   }
   a.t_NI = NI, a.t_R = R, a.t_Wt = Wt;
   a.n_bt = (a.B + NI - 1) / NI;
-  a.n_rt = a.pixel_major ? a.Ho : (a.HoWo > 1 ? (a.Ho + R - 1) / R : 1);
+  a.n_rt = (a.pixel_major || a.row_taps) ? a.Ho : (a.HoWo > 1 ? (a.Ho + R - 1) / R : 1);
   a.n_ct = a.pixel_major ? a.Wo : (a.HoWo > 1 ? (a.Wo + Wt - 1) / Wt : 1);
   a.m_tiles = a.n_bt * a.n_rt * a.n_ct;
   return NI * R * Wt;
