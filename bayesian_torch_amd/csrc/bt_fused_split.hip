@@ -52,7 +52,7 @@ static int launch_split_xm(FwdArgs& a, int mode, int xm, hipStream_t stream) {
     if (xm == 3) return launch_split_cfg<BM, 3, NPW, 3>(a, stream);
     if (xm == 4) return launch_split_cfg<BM, 3, NPW, 4>(a, stream);
     if constexpr (BM == 256) {
-      if (xm == 2) return launch_split_cfg<BM, 3, NPW, 2>(a, stream);
+      if (xm == 2) return launch_split_cfg<BM, 3, 8, 2>(a, stream);
     }
   }
   return launch_split_cfg<BM, 3, NPW, 0>(a, stream);
