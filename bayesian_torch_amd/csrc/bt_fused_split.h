@@ -234,6 +234,14 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
 
   const float* const xs = a.x + (long long)s * a.x_sample_stride;
   constexpr uint32_t kOOB = 0x80000000u;
+  // Offset of a guarded load: `off` when the element exists, else an out-of-range offset (the buffer load returns 0). As bit
+  // arithmetic on purpose: written as a select, the compiler sinks the offset computation into a branch per load, and the
+  // wait-count pass then drains the loads in flight at those block boundaries whenever two of them share a register
+  // (measured: 2.5x on the short-stage 1x1 layers of ResNet50 after an unrelated change moved the register allocation).
+  auto guard_off = [](bool in, uint32_t off) -> uint32_t {
+    const uint32_t m = 0u - (uint32_t)in;
+    return (off & m) | (0x80000000u & ~m);
+  };
   const int Cig4 = Cig;  // a multiple of 8 here
   const int pk_bytes = a.Co * T * Cig4 * 4;
   const __amdgpu_buffer_rsrc_t r_mu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mu_pk), 0, pk_bytes, 0x00020000);
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       //  consecutive lanes when one tap is active -- then write different banks; reads stay 16 distinct slots per lane group)
       l_off[i] = u < nunits ? st_ * W_STEP + hf * W_HALF + (n ^ ((2 * st_ + hf) & 7)) * 16 + cq * 8 : -1;
       u_ol[i] = ol;
-      u_live[i] = __ballot(rv && u < nunits) != 0ull;
+      u_live[i] = __builtin_amdgcn_readfirstlane(__ballot(rv && u < nunits) != 0ull ? 1 : 0) != 0;   // (an SGPR condition: the guarded blocks below must stay UNIFORM branches -- as exec-masked regions they made the compiler drain every outstanding load at their entry, 2.5x on the short-stage layers)
     }
     const int wave_u0 = __builtin_amdgcn_readfirstlane(ptid & ~63);
     if (stamp0) dbg_[213] = __builtin_amdgcn_s_memtime();
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       for (int i = 0; i < UMAX; ++i) {
         if (u_live[i]) {  // wave-uniform
           const bool in = l_off[i] >= 0 && oct0 + u_ol[i] < G8 && e_off[i] != (kOOB >> 2);
-          const uint32_t sb = in ? 4u * (e_off[i] + (uint32_t)(8 * oct0)) : kOOB;
+          const uint32_t sb = guard_off(in, 4u * (e_off[i] + (uint32_t)(8 * oct0)));
           mu[i] = ldf4(r_mu, sb), rs[i] = ldf4(r_rs, sb);
         }
       }
@@ -457,27 +465,27 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
           if constexpr (XM == 2) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-              const float4 v = ldf4(r_x, in ? (uint32_t)(it_off[i] + 16 * (8 * oc + c)) : kOOB);
+              const float4 v = ldf4(r_x, guard_off(in, (uint32_t)(it_off[i] + 16 * (8 * oc + c))));
               xv[i][4 * c] = v.x, xv[i][4 * c + 1] = v.y, xv[i][4 * c + 2] = v.z, xv[i][4 * c + 3] = v.w;
             }
           } else if constexpr (XM == 1) {
-            const float4 v0 = ldf4(r_x, in ? (uint32_t)(it_off[i] + 32 * oc) : kOOB), v1 = ldf4(r_x, in ? (uint32_t)(it_off[i] + 32 * oc + 16) : kOOB);
+            const float4 v0 = ldf4(r_x, guard_off(in, (uint32_t)(it_off[i] + 32 * oc))), v1 = ldf4(r_x, guard_off(in, (uint32_t)(it_off[i] + 32 * oc + 16)));
             xv[i][0] = v0.x, xv[i][1] = v0.y, xv[i][2] = v0.z, xv[i][3] = v0.w, xv[i][4] = v1.x, xv[i][5] = v1.y, xv[i][6] = v1.z, xv[i][7] = v1.w;
           } else if constexpr (XM == 3) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              const float4 v = ldf4(r_x, in ? (uint32_t)(it_off[i] + (8 * oc + c) * HWb) : kOOB);
+              const float4 v = ldf4(r_x, guard_off(in, (uint32_t)(it_off[i] + (8 * oc + c) * HWb)));
               xv[i][4 * c] = v.x, xv[i][4 * c + 1] = v.y, xv[i][4 * c + 2] = v.z, xv[i][4 * c + 3] = v.w;
             }
           } else if constexpr (XM == 4) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-              const float4 v = ldf4(r_x, in ? (uint32_t)(it_off[i] + (8 * oc + c) * HWb) : kOOB);
+              const float4 v = ldf4(r_x, guard_off(in, (uint32_t)(it_off[i] + (8 * oc + c) * HWb)));
               xv[i][4 * c] = v.x, xv[i][4 * c + 1] = v.y, xv[i][4 * c + 2] = v.z, xv[i][4 * c + 3] = v.w;
             }
           } else {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) xv[i][c] = ldf(r_x, in ? (uint32_t)(it_off[i] + (8 * oc + c) * HWb) : kOOB);
+            for (int c = 0; c < 8; ++c) xv[i][c] = ldf(r_x, guard_off(in, (uint32_t)(it_off[i] + (8 * oc + c) * HWb)));
           }
         }
       }

@@ -167,7 +167,7 @@ static int launch_split_one(FwdArgs& a, hipStream_t stream) {
   else if (xal && bm != 512 && a.row_taps && a.H == 2 && a.W == 2 && a.KW == 3 && a.PW == 1 && a.SW == 1 && a.DW == 1) xm = 2;   // a row tile's patch is the whole 2x2 plane
   else if (xal && a.pixel_major && a.H == 2 && a.W == 2 && a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.SH == 1 && a.SW == 1 && a.DH == 1 && a.DW == 1) xm = 2;
   if (bm == 512) return launch_split_xm<512, 4>(a, mode, xm, stream);
-  if (bm == 256) return launch_split_xm<256, 4>(a, mode, xm, stream);
+  if (bm == 256) return launch_split_xm<256, 8>(a, mode, xm, stream);
   return launch_split_xm<128, 8>(a, mode, xm, stream);
 }
 
