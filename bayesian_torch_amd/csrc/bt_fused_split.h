@@ -891,6 +891,33 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         cok[i] = n0 + co_l < a.Cog;
       }
       const int HoWo = a.Ho * a.Wo;
+      if (a.row_taps && t_Wt == 2 && (a.Wo & 1) == 0 && !FLIP) {
+        // Row tiles of two-pixel rows: columns 2i, 2i + 1 are the two pixels of one image's row -- 8 contiguous bytes per channel.
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;   // even
+            int bb, hh, ww;
+            const bool live = col_decode(wm * WTM + j * 32 + row, bb, hh, ww);   // (ww == 0; column + 1 is the same image's second pixel)
+            const uint32_t base = (uint32_t)((bb * a.Co + g * a.Cog + n0) * HoWo + hh * a.Wo + ww);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+              if (live && cok[i]) {
+                const uint32_t oi = base + (uint32_t)(((wn * TN + i) * 32 + li) * HoWo);
+                float v0 = __fadd_rn(__fmul_rn(__fadd_rn(acc[0][i][j][r], bsv[i]), scv[i]), shv[i]);
+                float v1 = __fadd_rn(__fmul_rn(__fadd_rn(acc[0][i][j][r + 1], bsv[i]), scv[i]), shv[i]);
+                if (res_s) {
+                  const float2 rr = *reinterpret_cast<const float2*>(res_s + oi);
+                  v0 = __fadd_rn(v0, rr.x), v1 = __fadd_rn(v1, rr.y);
+                }
+                v0 = (relu && v0 < 0.f) ? 0.f : v0, v1 = (relu && v1 < 0.f) ? 0.f : v1;
+                *reinterpret_cast<float2*>(out_s + oi) = make_float2(v0, v1);
+              }
+            }
+          }
+        }
+      } else
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
 #pragma unroll
