@@ -917,6 +917,34 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
             }
           }
         }
+      } else if (!pix && !a.row_taps && HoWo == 4 && t_R == a.Ho && t_Wt == a.Wo && !FLIP) {
+        // Tiles of whole four-pixel images: columns 4i .. 4i + 3 are one image's plane -- 16 contiguous bytes per channel.
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 8 * q + 4 * lh;   // a multiple of 4
+            int bb, hh, ww;
+            const bool live = col_decode(wm * WTM + j * 32 + row, bb, hh, ww);   // (pixel 0 of image bb)
+            const uint32_t base = (uint32_t)((bb * a.Co + g * a.Cog + n0) * HoWo);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+              if (live && cok[i]) {
+                const uint32_t oi = base + (uint32_t)(((wn * TN + i) * 32 + li) * HoWo);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(__fmul_rn(__fadd_rn(acc[0][i][j][4 * q + e], bsv[i]), scv[i]), shv[i]);
+                if (res_s) {
+                  const float4 rr = *reinterpret_cast<const float4*>(res_s + oi);
+                  v[0] = __fadd_rn(v[0], rr.x), v[1] = __fadd_rn(v[1], rr.y), v[2] = __fadd_rn(v[2], rr.z), v[3] = __fadd_rn(v[3], rr.w);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (relu && v[e] < 0.f) ? 0.f : v[e];
+                *reinterpret_cast<float4*>(out_s + oi) = make_float4(v[0], v[1], v[2], v[3]);
+              }
+            }
+          }
+        }
       } else
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
