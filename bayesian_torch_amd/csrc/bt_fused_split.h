@@ -891,7 +891,12 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         cok[i] = n0 + co_l < a.Cog;
       }
       const int HoWo = a.Ho * a.Wo;
-      if (a.row_taps && t_Wt == 2 && (a.Wo & 1) == 0 && !FLIP) {
+      auto outv = [&](int i, int j, int r, uint32_t oi) -> float {   // output-stage value of accumulator register r (before residual / ReLU)
+        float v = __fadd_rn(acc[0][i][j][r], bsv[i]);
+        if constexpr (FLIP) v = __fadd_rn(v, __fmul_rn(__fadd_rn(acc[NOP - 1][i][j][r], b1v[i]), hash_sign(skey_out, oi)));
+        return __fadd_rn(__fmul_rn(v, scv[i]), shv[i]);
+      };
+      if (a.row_taps && t_Wt == 2 && (a.Wo & 1) == 0) {
         // Row tiles of two-pixel rows: columns 2i, 2i + 1 are the two pixels of one image's row -- 8 contiguous bytes per channel.
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
@@ -905,8 +910,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
             for (int i = 0; i < TN; ++i) {
               if (live && cok[i]) {
                 const uint32_t oi = base + (uint32_t)(((wn * TN + i) * 32 + li) * HoWo);
-                float v0 = __fadd_rn(__fmul_rn(__fadd_rn(acc[0][i][j][r], bsv[i]), scv[i]), shv[i]);
-                float v1 = __fadd_rn(__fmul_rn(__fadd_rn(acc[0][i][j][r + 1], bsv[i]), scv[i]), shv[i]);
+                float v0 = outv(i, j, r, oi), v1 = outv(i, j, r + 1, oi + 1u);
                 if (res_s) {
                   const float2 rr = *reinterpret_cast<const float2*>(res_s + oi);
                   v0 = __fadd_rn(v0, rr.x), v1 = __fadd_rn(v1, rr.y);
@@ -917,7 +921,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
             }
           }
         }
-      } else if (!pix && !a.row_taps && HoWo == 4 && t_R == a.Ho && t_Wt == a.Wo && !FLIP) {
+      } else if (!pix && !a.row_taps && HoWo == 4 && t_R == a.Ho && t_Wt == a.Wo) {
         // Tiles of whole four-pixel images: columns 4i .. 4i + 3 are one image's plane -- 16 contiguous bytes per channel.
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
@@ -933,7 +937,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
                 const uint32_t oi = base + (uint32_t)(((wn * TN + i) * 32 + li) * HoWo);
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(__fmul_rn(__fadd_rn(acc[0][i][j][4 * q + e], bsv[i]), scv[i]), shv[i]);
+                for (int e = 0; e < 4; ++e) v[e] = outv(i, j, 4 * q + e, oi + (uint32_t)e);
                 if (res_s) {
                   const float4 rr = *reinterpret_cast<const float4*>(res_s + oi);
                   v[0] = __fadd_rn(v[0], rr.x), v[1] = __fadd_rn(v[1], rr.y), v[2] = __fadd_rn(v[2], rr.z), v[3] = __fadd_rn(v[3], rr.w);
