@@ -313,6 +313,41 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     }
   };
 
+  // The same staged tile read out by COLUMNS: maps whose rows are not 16-byte multiples (7x7, 14x14 rows of 7 / 14 pixels ...).
+  // A thread keeps one tile column (the thread count is a multiple of BM) and walks the channels: consecutive lanes store
+  // consecutive pixels of an image -- contiguous 4-byte stores instead of one scattered store per (lane = channel, pixel).
+  const bool stage_cols = !a.out_vec4 && !pix && !a.row_taps && a.Ho * a.Wo > 4;
+  auto readout_cols = [&](int pass, int t0) {
+    constexpr int SROW = BM + 4, NT_ = kThreadsAll;
+    static_assert(NT_ % BM == 0, "a thread keeps its column");
+    constexpr int RSTEP = NT_ / BM, NITc = (SROWS + RSTEP - 1) / RSTEP;
+    const float* const stage = smem + 4 * BN;
+    const int c = t0 % BM, row0 = t0 / BM;
+    int bq, hq, wq;
+    const bool mok = col_decode(c, bq, hq, wq);
+    const int HoWo_ = a.Ho * a.Wo;
+    const int co0 = pass * SROWS + row0;
+    const uint32_t obase = mok ? (uint32_t)(((bq * a.Co + g * a.Cog + n0 + co0) * a.Ho + hq) * a.Wo + wq) : 0u;
+    const int rows_ok = a.Cog - n0 - pass * SROWS < SROWS ? a.Cog - n0 - pass * SROWS : SROWS;
+    const float* const sp = stage + row0 * SROW + c;
+#pragma unroll 8
+    for (int k = 0; k < NITc; ++k) {
+      const int row = row0 + k * RSTEP;
+      const bool ok = mok && row < rows_ok;
+      const uint32_t oi = ok ? obase + (uint32_t)(k * RSTEP * HoWo_) : 0u;
+      const int rr = row < SROWS ? k * RSTEP : 0;
+      float v = sp[rr * SROW];
+      if constexpr (FLIP) {
+        const float d = sp[(SROWS + rr) * SROW];
+        const int co_l = ok ? co0 + k * RSTEP : 0;
+        v = __fadd_rn(__fmul_rn(__fadd_rn(v, __fmul_rn(d, hash_sign(skey_out, oi))), osc[co_l]), osh[co_l]);
+      }
+      if (res_s && ok) v = __fadd_rn(v, res_s[oi]);
+      v = (relu && v < 0.f) ? 0.f : v;
+      if (ok) out_s[oi] = v;
+    }
+  };
+
   const int prio_mode = dbg_ ? (int)dbg_[200] : 0;  // diagnostic build: 0 producers first (product), 1 none, 2 consumers first
   if (producer) {
     if (prio_mode == 0) __builtin_amdgcn_s_setprio(3);
@@ -636,13 +671,14 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       osh[ptid] = cv ? sh : 0.f;
     }
     __syncthreads();
-    if (a.out_vec4) {  // the consumers pass the output tile through LDS: same barriers and a share of the read-out
+    if (a.out_vec4 || stage_cols) {  // the consumers pass the output tile through LDS: same barriers and a share of the read-out
       __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         if (ps > 0) __syncthreads();
         __syncthreads();
-        readout_quads(ps, tid);
+        if (a.out_vec4) readout_quads(ps, tid);
+        else readout_cols(ps, tid);
       }
     }
   } else {
@@ -833,7 +869,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
     if (cstamp) dbg_[120] = __builtin_amdgcn_s_memtime();
 
     // ---- output stage + store (bt_fused_fast.h: lane = one channel, registers 4q..4q+3 = 4 consecutive positions) ----
-    if (a.out_vec4) {
+    if (a.out_vec4 || stage_cols) {
       constexpr int SROW = BM + 4;
       static_assert((4 * BN + NOP * SROWS * SROW) * 4 <= 2 * (W_BYTES + X_BYTES), "output staging fits the operand buffers");
       float* const stage = smem + 4 * BN;
@@ -876,7 +912,8 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         if (cstamp) dbg_[121] = __builtin_amdgcn_s_memtime();
         __syncthreads();
         if (cstamp) dbg_[122] = __builtin_amdgcn_s_memtime();
-        readout_quads(ps, tid);
+        if (a.out_vec4) readout_quads(ps, tid);
+        else readout_cols(ps, tid);
         if (cstamp) dbg_[123] = __builtin_amdgcn_s_memtime();
       }
     } else {
