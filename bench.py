@@ -173,6 +173,24 @@ def cpu_baseline(w, budget_s=12.0, budget_1t=8.0):
                 one_thread=dict(value=n1 / dt1, unit="MC-samples/s", cores=1, sample=f"{n1} samples, {dt1:.1f} s"))
 
 
+def _offline_traffic(workload):
+    """The newest committed PMC summary of the default command (profiles/r*_bench_summary.json), LABELLED as a file read: it was
+    not measured by this run. FETCH_SIZE / WRITE_SIZE in the counters' own units (KB) per fused launch, averaged over the step's
+    launches; the guide's x2 correction for 16-byte fetch streams is NOT applied."""
+    if workload != "cfg3":
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_bench_summary.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return dict(source=os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__))) + " (offline rocprofv3 PMC passes; not measured in this run)",
+                    fetch_kb_per_launch=round(d["fetch"]["fused"]["per_launch"], 1), write_kb_per_launch=round(d["write"]["fused"]["per_launch"], 1))
+    except Exception:
+        return None
+
+
 def parity_check(w, dev):
     """One MC sample through the same kernels (on-chip draws, unfused so every layer's own output is visible), each
     Bayesian layer's output and the logits against the CPU oracle ON THE SAME DRAWS (materialised from the counters).
@@ -418,6 +436,7 @@ def main():
         roof = dict(bound="mfma", achieved=round(ach, 3), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                     frac_effective=round(tot["eff"] / tot["ms"] / 1e9 / peak, 4), frac_nominal=round(tot["nom"] / tot["ms"] / 1e9 / peak, 4),
                     traffic=None, traffic_note="HBM bytes are measured offline with rocprofv3 PMC passes of this same command (tools/profile_bench.sh -> profiles/): PMC cannot run inside the process",
+                    traffic_offline=_offline_traffic(args.workload),
                     kernel=dom_name, kernel_share_of_launch_time=round(dom["ms"] / tot["ms"], 4), kernel_launches_per_step=dom["launches"],
                     kernel_achieved=round(dom_ach, 3), kernel_frac=round(dom_ach / peak, 4), kernel_avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
                     launches_per_step=nl, avg_launch_ms=round(tot["ms"] / nl, 4),
