@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BT_LIB_PATH") or os.path.join(_HERE, "libbtorch_hip.so")   # BT_LIB_PATH: a diagnostic build (tools/stamps.py)
 WORKSPACE_BYTES = 65536
 KL_MAX_SEGMENTS = 64
+PACK_MAX_SEGMENTS = 64
 KL_RHO_IS_SIGMA = 1
 KL_PRIOR_LAPLACE = 2
 PRIOR_NORMAL, PRIOR_LAPLACE = 0, 1
@@ -40,6 +41,11 @@ class bt_epilogue(C.Structure):
                 ("pool", C.c_int32)]
 
 
+class bt_pack_seg(C.Structure):
+    _fields_ = [(n, _vp) for n in ("mu_w", "rho_w", "src_mu", "src_rho", "mu_packed", "sigma_packed", "state")] \
+        + [("Co", C.c_int64), ("Ci", C.c_int64), ("taps", C.c_int64), ("force", C.c_int32), ("reserved", C.c_int32)]
+
+
 class bt_conv2d_geom(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "Ci", "H", "W", "Co", "kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw", "groups")]
 
@@ -52,6 +58,7 @@ _PROTOS = {
     "bt_version": (C.c_int, []),
     "bt_last_error_string": (C.c_char_p, []),
     "bt_last_kernel_name": (C.c_char_p, []),
+    "bt_last_launch_info": (C.c_int, [C.POINTER(C.c_int64), C.c_int32]),
     "bt_set_contraction": (C.c_int, [C.c_int]),
     "bt_conv2d_bwd_workspace": (C.c_size_t, [C.POINTER(bt_conv2d_geom), C.c_int32]),
     "bt_conv2d_bwd": (C.c_int, [C.POINTER(bt_conv2d_geom), C.c_int32, C.c_int32, _vp, C.c_int64, _vp, C.POINTER(bt_params), C.POINTER(bt_draws),
@@ -65,6 +72,7 @@ _PROTOS = {
     "bt_flipout_conv2d_fwd": (C.c_int, [C.POINTER(bt_conv2d_geom), C.c_int32] + _FWD_TAIL),
     "bt_kl_normal": (C.c_int, [C.c_int32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int64),
                                C.POINTER(C.c_int32), C.c_uint32, _vp, _vp, C.c_size_t, _vp]),
+    "bt_pack_sync": (C.c_int, [C.c_int32, C.POINTER(bt_pack_seg), _vp, C.c_size_t, _vp]),
     "bt_pack_params": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp]),
     "bt_rng_normal_fill": (C.c_int, [C.POINTER(bt_rng), C.c_uint32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]),
     "bt_rng_sign_fill": (C.c_int, [C.POINTER(bt_rng), C.c_uint32, C.c_int32, C.c_int64, _vp, _vp]),
@@ -91,6 +99,16 @@ def lib():
                     fn.restype, fn.argtypes = res, args
                 _lib = handle
     return _lib
+
+
+LAUNCH_INFO_FIELDS = ("workgroups", "m_tiles", "n_tiles", "S", "t_NI", "t_R", "t_Wt", "pixel_major", "row_tiles", "kl_slices", "groups", "n_bt", "n_rt", "n_ct", "fused_kl")
+
+
+def last_launch_info():
+    """Tile geometry of the calling thread's last fused-forward launch (bt_last_launch_info) as a dict."""
+    v = (C.c_int64 * 16)()
+    check(lib().bt_last_launch_info(v, 16))
+    return dict(zip(LAUNCH_INFO_FIELDS, (int(x) for x in v)))
 
 
 ERR_UNSUPPORTED = -2  # BT_ERR_UNSUPPORTED

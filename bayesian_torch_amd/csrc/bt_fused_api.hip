@@ -10,6 +10,7 @@ int launch_flipout(bool linear, FwdArgs& a, hipStream_t stream);
 int launch_flipout_inj(bool linear, FwdArgs& a, hipStream_t stream);
 
 static unsigned long long* g_dbg = nullptr;
+static thread_local long long g_launch_info[16] = {};
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const float* x, int64_t x_sample_stride, const bt_params* p,
@@ -102,6 +103,10 @@ static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const flo
   int rc;
   if (inj) rc = flip ? launch_flipout_inj(linear, a, (hipStream_t)stream) : launch_reparam_inj(linear, a, (hipStream_t)stream);
   else rc = flip ? launch_flipout(linear, a, (hipStream_t)stream) : launch_reparam(linear, a, (hipStream_t)stream);
+  if (rc == BT_OK) {   // tile geometry of the launch just made (bt_last_launch_info)
+    const long long v[16] = {a.total_blocks, a.m_tiles, a.n_tiles, a.S, a.t_NI, a.t_R, a.t_Wt, a.pixel_major, a.row_taps, a.kl_slices, a.G, a.n_bt, a.n_rt, a.n_ct, a.do_kl, 0};
+    for (int i = 0; i < 16; ++i) g_launch_info[i] = v[i];
+  }
   if (rc == BT_OK && kl_after) {
     const float* mu[2] = {p->mu_w, p->mu_b};
     const float* rho[2] = {p->rho_w, p->rho_b};
@@ -141,6 +146,12 @@ extern "C" int bt_flipout_conv2d_fwd(const bt_conv2d_geom* g, int32_t S, const f
                                      const bt_draws* d, const bt_epilogue* ep, float* out, float* kl_out, void* ws, size_t ws_bytes, bt_stream_t stream) {
   if (!g) return bt::set_error(BT_ERR_BAD_ARG, "bt_flipout_conv2d_fwd: null geometry");
   return bt::run(true, false, *g, S, x, x_sample_stride, p, d, ep, out, kl_out, ws, ws_bytes, stream, "bt_flipout_conv2d_fwd");
+}
+
+extern "C" int bt_last_launch_info(int64_t* out, int32_t n) {
+  if (!out || n <= 0) return bt::set_error(BT_ERR_BAD_ARG, "bt_last_launch_info: bad argument");
+  for (int i = 0; i < n; ++i) out[i] = i < 16 ? (int64_t)bt::g_launch_info[i] : 0;
+  return BT_OK;
 }
 
 // Diagnostic hook (not part of include/bt_hip.h): device buffer of >= 256 u64 that block 0 of every fused launch

@@ -698,14 +698,17 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       kl_v4 = ((((uintptr_t)a.mu_w | (uintptr_t)a.rho_w | (uintptr_t)a.pmu_w | (uintptr_t)a.psig_w) & 15u) == 0);
       kl_i = lo + 4ll * ptid;
     }
-    auto kl_group = [&]() {  // -> false when this thread has no whole float4 group left
-      if (!(kl_v4 && kl_i + 3 < kl_hi)) return false;
-      const float4 m4 = *reinterpret_cast<const float4*>(a.mu_w + kl_i), r4 = *reinterpret_cast<const float4*>(a.rho_w + kl_i);
-      const float4 p4 = *reinterpret_cast<const float4*>(a.pmu_w + kl_i), q4 = *reinterpret_cast<const float4*>(a.psig_w + kl_i);
+    auto kl_terms = [&](const float4& m4, const float4& r4, const float4& p4, const float4& q4) {
       const float t0 = kl_term(m4.x, softplus(r4.x), p4.x, q4.x) + kl_term(m4.y, softplus(r4.y), p4.y, q4.y);
       const float t1 = kl_term(m4.z, softplus(r4.z), p4.z, q4.z) + kl_term(m4.w, softplus(r4.w), p4.w, q4.w);
       kl_acc += (double)t0 + (double)t1;
       kl_i += 1024;
+    };
+    auto kl_group = [&]() {  // -> false when this thread has no whole float4 group left
+      if (!(kl_v4 && kl_i + 3 < kl_hi)) return false;
+      const float4 m4 = *reinterpret_cast<const float4*>(a.mu_w + kl_i), r4 = *reinterpret_cast<const float4*>(a.rho_w + kl_i);
+      const float4 p4 = *reinterpret_cast<const float4*>(a.pmu_w + kl_i), q4 = *reinterpret_cast<const float4*>(a.psig_w + kl_i);
+      kl_terms(m4, r4, p4, q4);
       return true;
     };
     auto kl_finish = [&]() {
@@ -859,7 +862,8 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         }
       }
       if (cstamp && st < 60) dbg_[2 + 2 * st + 1] = __builtin_amdgcn_s_memtime();
-      if (kl_block) kl_group();
+      if (kl_block) kl_group();   // (fetching the group one stage ahead was tried in round 3: the 16 registers it holds across the MFMA loop spill on
+                                  //  the 256-wide tiles -- layer3 +5..19 % -- and layer4's 128-wide launches did not move: dropped)
       __syncthreads();
     }
     if (kl_block) kl_finish();
@@ -933,25 +937,37 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         if constexpr (FLIP) v = __fadd_rn(v, __fmul_rn(__fadd_rn(acc[NOP - 1][i][j][r], b1v[i]), hash_sign(skey_out, oi)));
         return __fadd_rn(__fmul_rn(v, scv[i]), shv[i]);
       };
+      // In all three forms below the residual values of a column group are fetched in ONE batch before its first store: written
+      // as load -> add -> store per element, the loads cannot be moved above the stores (the compiler has to assume out and
+      // residual alias) and every element pays a full memory round trip -- 17 K of layer3's 170 K cycles per workgroup.
       if (a.row_taps && t_Wt == 2 && (a.Wo & 1) == 0) {
         // Row tiles of two-pixel rows: columns 2i, 2i + 1 are the two pixels of one image's row -- 8 contiguous bytes per channel.
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
+          uint32_t base[8];
+          bool live[8];
+          float2 rr[8][TN];
 #pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;   // even
+          for (int r2 = 0; r2 < 8; ++r2) {
+            const int r = 2 * r2, row = (r & 3) + 8 * (r >> 2) + 4 * lh;   // even
             int bb, hh, ww;
-            const bool live = col_decode(wm * WTM + j * 32 + row, bb, hh, ww);   // (ww == 0; column + 1 is the same image's second pixel)
-            const uint32_t base = (uint32_t)((bb * a.Co + g * a.Cog + n0) * HoWo + hh * a.Wo + ww);
+            live[r2] = col_decode(wm * WTM + j * 32 + row, bb, hh, ww);   // (ww == 0; column + 1 is the same image's second pixel)
+            base[r2] = live[r2] ? (uint32_t)((bb * a.Co + g * a.Cog + n0) * HoWo + hh * a.Wo + ww) : 0u;
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
-              if (live && cok[i]) {
-                const uint32_t oi = base + (uint32_t)(((wn * TN + i) * 32 + li) * HoWo);
+              rr[r2][i] = make_float2(0.f, 0.f);
+              if (res_s && live[r2] && cok[i]) rr[r2][i] = *reinterpret_cast<const float2*>(res_s + base[r2] + (uint32_t)(((wn * TN + i) * 32 + li) * HoWo));
+            }
+          }
+#pragma unroll
+          for (int r2 = 0; r2 < 8; ++r2) {
+            const int r = 2 * r2;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+              if (live[r2] && cok[i]) {
+                const uint32_t oi = base[r2] + (uint32_t)(((wn * TN + i) * 32 + li) * HoWo);
                 float v0 = outv(i, j, r, oi), v1 = outv(i, j, r + 1, oi + 1u);
-                if (res_s) {
-                  const float2 rr = *reinterpret_cast<const float2*>(res_s + oi);
-                  v0 = __fadd_rn(v0, rr.x), v1 = __fadd_rn(v1, rr.y);
-                }
+                if (res_s) v0 = __fadd_rn(v0, rr[r2][i].x), v1 = __fadd_rn(v1, rr[r2][i].y);
                 v0 = (relu && v0 < 0.f) ? 0.f : v0, v1 = (relu && v1 < 0.f) ? 0.f : v1;
                 *reinterpret_cast<float2*>(out_s + oi) = make_float2(v0, v1);
               }
@@ -962,23 +978,31 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
         // Tiles of whole four-pixel images: columns 4i .. 4i + 3 are one image's plane -- 16 contiguous bytes per channel.
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
+          uint32_t base[4];
+          bool live[4];
+          float4 rr[4][TN];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int row = 8 * q + 4 * lh;   // a multiple of 4
             int bb, hh, ww;
-            const bool live = col_decode(wm * WTM + j * 32 + row, bb, hh, ww);   // (pixel 0 of image bb)
-            const uint32_t base = (uint32_t)((bb * a.Co + g * a.Cog + n0) * HoWo);
+            live[q] = col_decode(wm * WTM + j * 32 + row, bb, hh, ww);   // (pixel 0 of image bb)
+            base[q] = live[q] ? (uint32_t)((bb * a.Co + g * a.Cog + n0) * HoWo) : 0u;
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
-              if (live && cok[i]) {
-                const uint32_t oi = base + (uint32_t)(((wn * TN + i) * 32 + li) * HoWo);
+              rr[q][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (res_s && live[q] && cok[i]) rr[q][i] = *reinterpret_cast<const float4*>(res_s + base[q] + (uint32_t)(((wn * TN + i) * 32 + li) * HoWo));
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+              if (live[q] && cok[i]) {
+                const uint32_t oi = base[q] + (uint32_t)(((wn * TN + i) * 32 + li) * HoWo);
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = outv(i, j, 4 * q + e, oi + (uint32_t)e);
-                if (res_s) {
-                  const float4 rr = *reinterpret_cast<const float4*>(res_s + oi);
-                  v[0] = __fadd_rn(v[0], rr.x), v[1] = __fadd_rn(v[1], rr.y), v[2] = __fadd_rn(v[2], rr.z), v[3] = __fadd_rn(v[3], rr.w);
-                }
+                if (res_s) v[0] = __fadd_rn(v[0], rr[q][i].x), v[1] = __fadd_rn(v[1], rr[q][i].y), v[2] = __fadd_rn(v[2], rr[q][i].z), v[3] = __fadd_rn(v[3], rr[q][i].w);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = (relu && v[e] < 0.f) ? 0.f : v[e];
                 *reinterpret_cast<float4*>(out_s + oi) = make_float4(v[0], v[1], v[2], v[3]);
@@ -989,20 +1013,29 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
       } else
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
+        uint32_t base[16];
+        bool live[16];
+        float rr[16][TN];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
           int bb, hh, ww;
-          const bool live = col_decode(wm * WTM + j * 32 + row, bb, hh, ww);
-          const uint32_t base = (uint32_t)((bb * a.Co + g * a.Cog + n0) * HoWo + hh * a.Wo + ww);  // channel n0 of this pixel
+          live[r] = col_decode(wm * WTM + j * 32 + row, bb, hh, ww);
+          base[r] = live[r] ? (uint32_t)((bb * a.Co + g * a.Cog + n0) * HoWo + hh * a.Wo + ww) : 0u;  // channel n0 of this pixel
 #pragma unroll
           for (int i = 0; i < TN; ++i) {
-            if (live && cok[i]) {
-              const uint32_t oi = base + (uint32_t)(((wn * TN + i) * 32 + li) * HoWo);
-              float v = __fadd_rn(acc[0][i][j][r], bsv[i]);
-              if constexpr (FLIP) v = __fadd_rn(v, __fmul_rn(__fadd_rn(acc[NOP - 1][i][j][r], b1v[i]), hash_sign(skey_out, oi)));
-              v = __fadd_rn(__fmul_rn(v, scv[i]), shv[i]);
-              if (res_s) v = __fadd_rn(v, res_s[oi]);
+            rr[r][i] = 0.f;
+            if (res_s && live[r] && cok[i]) rr[r][i] = res_s[base[r] + (uint32_t)(((wn * TN + i) * 32 + li) * HoWo)];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+          for (int i = 0; i < TN; ++i) {
+            if (live[r] && cok[i]) {
+              const uint32_t oi = base[r] + (uint32_t)(((wn * TN + i) * 32 + li) * HoWo);
+              float v = outv(i, j, r, oi);
+              if (res_s) v = __fadd_rn(v, rr[r][i]);
               v = (relu && v < 0.f) ? 0.f : v;
               out_s[oi] = v;
             }

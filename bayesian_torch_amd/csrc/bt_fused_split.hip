@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "bt_fused_split_quad.h"
+#include "bt_fused_split_direct.h"
 #include "bt_fused_split_host.h"
 
 namespace bt {
@@ -118,6 +119,45 @@ static int launch_quad(FwdArgs& a, int mode, hipStream_t stream) {
   return a.ep_pool ? launch_quad_cfg<true>(a, mode, stream) : launch_quad_cfg<false>(a, mode, stream);
 }
 
+// 1x1 / stride-1 convolutions with K <= 256 and many pixels (the bottleneck ResNets' expanding / reducing layers): the persistent
+// kernel of bt_fused_split_direct.h. Eligibility is geometric (never a matter of S or of the launch split), and its arithmetic is the
+// general kernel's, so a layer's results do not depend on which of the two serves it.
+static std::atomic<int> g_direct_off{0};
+static int launch_direct(FwdArgs& a, hipStream_t stream) {
+  if (g_direct_off.load(std::memory_order_relaxed)) return 1;
+  if (a.KH != 1 || a.KW != 1 || a.SH != 1 || a.SW != 1 || a.PH || a.PW || a.ep_pool) return 1;
+  if ((a.Cig & 63) || a.Cig > kDirectMaxK || a.M < 8192) return 1;
+  a.n_tiles = (a.Cog + 63) / 64;
+  const long long pairs = (long long)a.G * a.n_tiles * a.S;
+  const int nsub = (a.M + 63) / 64;
+  // chunks of the pixel range per (group, channel tile, sample): ~1024 workgroups in all (four per CU: the tail of an uneven split
+  // is a quarter of a workgroup's work), each with at least 64 sub-tiles (8 per wave) to walk
+  long long chunks = (1024 + pairs - 1) / pairs;
+  if (chunks > nsub / 64) chunks = nsub / 64;
+  if (chunks < 1) chunks = 1;
+  const int spc = (int)((nsub + chunks - 1) / chunks);
+  chunks = (nsub + spc - 1) / spc;
+  const long long total = pairs * chunks;
+  if (total <= 0 || total > 0x7FFFFFFFll) return 1;
+  a.m_tiles = (int)chunks, a.t_NI = spc, a.t_R = 1, a.t_Wt = 64, a.n_bt = (int)chunks, a.n_rt = a.n_ct = 1;
+  a.total_blocks = (int)total;
+  a.kl_slices = total < 256 ? (int)total : 256;
+  a.inv_n_tiles = inv_u32(a.n_tiles, total), a.inv_m_tiles = inv_u32(a.m_tiles, total), a.inv_S = inv_u32(a.S, total);
+  a.inv_rw = inv_u32(a.HW, (long long)a.M + 64);   // pixel index -> (image, position)
+  const int lds = direct_lds_bytes(a.Cig);
+  static bool flags[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return set_error(BT_ERR_HIP_BASE, "fused forward (split, direct): hipGetDevice failed");
+  if (!flags[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fused_split_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, direct_lds_bytes(kDirectMaxK)) != hipSuccess)
+      return set_error(BT_ERR_HIP_BASE, "fused forward (split, direct): cannot raise the dynamic LDS limit");
+    flags[dev] = true;
+  }
+  note_kernel("fused_split_direct_kernel<64,8x64,bf16x3,6 terms,resident W>");
+  hipLaunchKernelGGL(fused_split_direct_kernel, dim3((unsigned)a.total_blocks), dim3(kDirectThreads), lds, stream, a);
+  return check_launch("fused forward (split, direct)");
+}
+
 // Returns BT_OK when the launch was taken, 1 when this flavour does not apply (the caller runs the fp32 kernels), < 0 on error.
 static int launch_split_one(FwdArgs& a, hipStream_t stream) {
   const int mode = contraction_mode();
@@ -127,6 +167,11 @@ static int launch_split_one(FwdArgs& a, hipStream_t stream) {
   if (a.Cig <= 4) return launch_quad(a, mode, stream);   // the stems
   // whole channel octets, at most 9 taps, no fused pooling
   if ((a.Cig & 7) || a.T > 9 || a.ep_pool) return 1;
+  if (mode != 2) {
+    FwdArgs d = a;
+    const int rcd = launch_direct(d, stream);
+    if (rcd <= 0) { a = d; return rcd; }
+  }
   const int Mdom = a.pixel_major ? a.B : a.M;
   if (Mdom < 112) return 1;
   a.n_tiles = (a.Cog + 63) / 64;
@@ -197,6 +242,9 @@ int launch_split(FwdArgs& a, hipStream_t stream) {
 }
 
 }  // namespace bt
+
+// Test hook (not part of include/bt_hip.h): 1 keeps 1x1 convolutions off the direct kernel, so a test can compare the two flavours.
+extern "C" void bt_debug_disable_direct(int off) { bt::g_direct_off.store(off ? 1 : 0, std::memory_order_relaxed); }
 
 // Contraction arithmetic of the fused forwards (process-wide knob; also env BT_CONTRACTION = f32 | bf16x3 | bf16x2):
 // 0 automatic -- exact bf16x3 split (6 product terms, fp32 accumulate) on the bf16 matrix pipe wherever the launch is eligible,

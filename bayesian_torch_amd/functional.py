@@ -159,6 +159,42 @@ def pack_params(mu_w, rho_w):
     return mp, sp
 
 
+def pack_buffers(Co, Ci, taps, device):
+    """Persistent storage of one layer's pack: (mu_packed, sigma_packed, state) -- state = the 4 device words bt_pack_sync keeps
+    (accumulator, fingerprint of the packed copy, dirty flag of the last call, rebuild count)."""
+    C4 = (Ci + 3) // 4 * 4
+    mp = torch.empty((Co, taps, C4), dtype=torch.float32, device=device)
+    return mp, torch.empty_like(mp), torch.zeros(4, dtype=torch.int64, device=device)
+
+
+def pack_sync(segments, owner="pack"):
+    """segments: list of dict(mu, rho, src_mu|None, src_rho|None, mu_packed, sigma_packed, state, Co, Ci, taps, force) on ONE device.
+    Re-packs, ON THE DEVICE and in the current stream, exactly the layers whose (mu, rho) no longer match the fingerprint their pack
+    was built from (bt_pack_sync: two launches per 64 layers, no host synchronisation, graph-capturable)."""
+    if not segments:
+        return
+    L = _lib.lib()
+    dev = segments[0]["mu"].device
+    for c0 in range(0, len(segments), _lib.PACK_MAX_SEGMENTS):
+        chunk = segments[c0:c0 + _lib.PACK_MAX_SEGMENTS]
+        arr = (_lib.bt_pack_seg * len(chunk))()
+        keep = []
+        for i, sg in enumerate(chunk):
+            mu, rho = _lib.dev_f32(sg["mu"], "mu_w"), _lib.dev_f32(sg["rho"], "rho_w")
+            smu = _lib.dev_f32(sg.get("src_mu"), "src_mu")
+            srho = _lib.dev_f32(sg.get("src_rho"), "src_rho")
+            if mu.device != dev:
+                raise RuntimeError("pack_sync: all layers of one call must live on one device")
+            keep.append((mu, rho, smu, srho))
+            n_src = (smu if smu is not None else mu).numel()
+            if n_src != sg["Co"] * sg["Ci"] * sg["taps"] or mu.numel() != n_src or rho.numel() != n_src:
+                raise RuntimeError("pack_sync: geometry does not match the parameter tensors")
+            arr[i] = _lib.bt_pack_seg(mu.data_ptr(), rho.data_ptr(), _lib.ptr(smu), _lib.ptr(srho), sg["mu_packed"].data_ptr(), sg["sigma_packed"].data_ptr(),
+                                      sg["state"].data_ptr(), sg["Co"], sg["Ci"], sg["taps"], 1 if sg.get("force") else 0, 0)
+        with _lib.on(dev):
+            _lib.check(L.bt_pack_sync(len(chunk), arr, _lib.workspace((owner, "pack"), dev).data_ptr(), _lib.WORKSPACE_BYTES, _lib.stream_ptr(dev)))
+
+
 def mc_epilogue(logits):
     """logits [S, B, C] -> packed [B*C + B + B*C] = [sum_s softmax | sum_s entropy | sum_s logits]."""
     logits = _lib.dev_f32(logits, "logits")

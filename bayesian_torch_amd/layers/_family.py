@@ -106,7 +106,8 @@ class FamilyConvLayer(FusedBayesLayer):
             Do = xw.shape[2]
             x = xw.permute(0, 2, 1, 5, 3, 4).reshape(n0 * Do, x.shape[1] * ks[0], x.shape[3], x.shape[4])
             conv = dict(stride=s[1:], padding=p[1:], dilation=d[1:], groups=self.groups)
-            back = lambda o: o.reshape(n0, Do, o.shape[1], o.shape[2], o.shape[3]).permute(0, 2, 1, 3, 4)
+            # (the leading dimension comes from the launch's output: under mc_samples it holds S * n0 * Do rows even when x was shared)
+            back = lambda o: o.reshape(-1, Do, o.shape[1], o.shape[2], o.shape[3]).permute(0, 2, 1, 3, 4)
         return x.contiguous(), conv, back
 
     def _sign_out_eq(self, t):
@@ -118,14 +119,47 @@ class FamilyConvLayer(FusedBayesLayer):
             return t.permute(0, 1, 3, 2, 4, 5).reshape(S, B * Do, Co, t.shape[4], t.shape[5]).contiguous()
         return t.contiguous()
 
-    def _packed(self):
-        mu, rho = self._w("mu"), self._w("rho")
-        key = (mu._version, mu.data_ptr(), rho._version, rho.data_ptr())
-        c = self._sigma_cache
-        if (self.training and torch.is_grad_enabled()) or c is None or c[0] != key:
-            c = (key, F.pack_params(self._w_eq(mu.detach()), self._w_eq(rho.detach())))
-            self._sigma_cache = None if (self.training and torch.is_grad_enabled()) else c
-        return c[1]
+    def _pack_source(self):
+        return self._w_eq(self._w("mu").detach()), self._w_eq(self._w("rho").detach())
+
+    def _w_nat(self, t, lead=0):
+        """Inverse of _w_eq: [lead...][Co][Cig'][kh][kw] of the Conv2d launch -> this class's own kernel layout."""
+        nd, g = self._nd, self.groups
+        ks = tuple(self._w("mu").shape[2:])
+        L = tuple(t.shape[:lead])
+        if nd == 1:
+            t = t.squeeze(lead + 2)
+        elif nd == 3:
+            t = t.reshape(L + (t.shape[lead], t.shape[lead + 1] // ks[0]) + ks)
+        if self._transposed:
+            t = t.flip(tuple(range(lead + 2, lead + 2 + nd)))
+            Co, Cig = t.shape[lead], t.shape[lead + 1]
+            t = t.reshape(L + (g, Co // g, Cig) + ks).transpose(lead + 1, lead + 2).reshape(L + (g * Cig, Co // g) + ks)
+        return t.contiguous()
+
+    def materialize_last_draw(self):
+        """The last forward's draw in the REFERENCE's layouts where one exists: eps_w [S, *kernel], eps_b [S, Co]. The on-chip
+        Flipout signs are defined over the Conv2d launch's operands (``sign_in_eq`` / ``sign_out_eq``: the re-arranged x and the
+        launch's output): a transposed convolution's zero-upsampled x carries one sign per real element like the reference, Conv3d's
+        depth-unfolded x one sign per (element, depth window) -- see DESIGN.md 4.6."""
+        if self._last is None:
+            raise RuntimeError("no forward has run yet")
+        st = self._last
+        if st["draw"] is not None:
+            d = dict(st["draw"])
+            d["eps_w"] = self._w_nat(d["eps_w"], lead=1)
+            return d
+        seed, call_base, call, lid, sample0 = st["rng"]
+        if call_base is not None:
+            raise RuntimeError("draws made under a graph call_base cannot be replayed after the word advanced")
+        dev, S = self._w("mu").device, st["S"]
+        res = dict(eps_w=self._w_nat(F.rng_fill_normal(seed, call, lid, sample0, 0, S, st["w_eq_shape"], dev), lead=1))
+        if self.mu_bias is not None:
+            res["eps_b"] = F.rng_fill_normal(seed, call, lid, sample0, 1, S, (self.out_channels,), dev)
+        if self._flip:
+            res["sign_in_eq"] = F.rng_fill_sign(seed, call, lid, sample0, 2, S, st["x_shape"], dev)
+            res["sign_out_eq"] = F.rng_fill_sign(seed, call, lid, sample0, 3, S, st["out_shape"], dev)
+        return res
 
     # ------------------------------------------------------------------ forward
     def forward(self, input, return_kl=True):
@@ -176,6 +210,9 @@ class FamilyConvLayer(FusedBayesLayer):
             out, _ = F.fused_forward(xe, mu_e, rho_e, self.mu_bias, self.rho_bias, flip=self._flip, conv=conv, S=S, shared_x=shared,
                                      eps_w=draw.get("eps_w"), eps_b=draw.get("eps_b"), sign_in=draw.get("sign_in"), sign_out=draw.get("sign_out"),
                                      seed=seed, call=call, layer_id=self._layer_id, sample0=sample0, call_base=call_base, packed=self._packed())
+        Be = xe.shape[0] // (1 if shared else S)
+        self._last = dict(draw=draw or None, rng=(seed, call_base, call, self._layer_id, sample0), S=S, kernel=_lib.lib().bt_last_kernel_name().decode(),
+                          w_eq_shape=tuple(mu_e.shape), x_shape=(Be,) + tuple(xe.shape[1:]), out_shape=(Be,) + tuple(out.shape[1:]))
         out = back(out).contiguous()
         kl = self.kl_loss() if want_kl else None
         if collect:

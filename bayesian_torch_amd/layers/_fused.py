@@ -50,8 +50,9 @@ class FusedBayesLayer(BaseVariationalLayer_):
             self.register_parameter("rho_bias", None)
             for b in ("eps_bias", "prior_bias_mu", "prior_bias_sigma"):
                 self.register_buffer(b, None, persistent=False)
-        self._layer_id = rng.new_layer_id()   # unique per constructed layer; dnn_to_bnn / rng.assign_layer_ids renumber by position
-        self._sigma_cache = None   # ((versions, pointers), (mu_packed, sigma_packed)): a pure function of (mu, rho)
+        self._layer_id = rng.new_layer_id()   # RNG coordinate; dnn_to_bnn / rng.assign_layer_ids renumber it by position
+        self._pack = None          # (key, mu_packed, sigma_packed, state): persistent buffers, kept in step by bt_pack_sync
+        self._pack_force = False
         self._last = None
         self.post_relu = False    # fused output stage, set by bayesian_torch_amd.fuse (inference-time folding)
         self.post_pool = False    # ... followed by MaxPool2d(3, 2, 1) (fuse.fold_maxpool: the ResNet stem)
@@ -61,6 +62,12 @@ class FusedBayesLayer(BaseVariationalLayer_):
         self.init_parameters()
         self.quant_prepare = False
 
+    @property
+    def _ws_id(self):
+        """Key of this layer's KL / pack workspaces: unique among live layers (copies of a model included), unlike the positional
+        RNG coordinate ``_layer_id`` -- two converted models may run concurrently on different streams."""
+        return id(self)
+
     def _init_scalars(self):
         mu0, rho0 = self.posterior_mu_init, self.posterior_rho_init
         if isinstance(mu0, tuple):   # the Reparameterization classes keep 1-tuples (trailing commas in the reference)
@@ -68,18 +75,13 @@ class FusedBayesLayer(BaseVariationalLayer_):
         return mu0, rho0
 
     def invalidate_pack(self):
-        """Drop the packed (mu, sigma) copy the fast kernel reads. Needed after writing a parameter through ``.data``
-        (``p.data.copy_()`` / ``.normal_()`` do not bump ``p._version``, which is what the cache is keyed on);
-        init_parameters, MOPED initialisation and load_state_dict call it themselves. A captured ``McGraph`` bakes the
-        pack's address in: re-capture after a parameter update."""
-        self._sigma_cache = None
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        super()._load_from_state_dict(*args, **kwargs)
-        self._sigma_cache = None
+        """Force a rebuild of the packed (mu, sigma) copy at the next forward. Never NEEDED: every forward checks a device-side
+        fingerprint of (mu, rho) against the one its pack was built from (bt_pack_sync), so writes through ``.data``
+        (``p.data.copy_()`` / ``.normal_()``: the reference's own idiom in dnn_to_bnn / MOPED, invisible to ``p._version``),
+        optimizer steps and load_state_dict are all picked up. Kept for callers of the round-2 API."""
+        self._pack_force = True
 
     def init_parameters(self):
-        self._sigma_cache = None
         mu0, rho0 = self._init_scalars()
         self.prior_weight_mu.fill_(self.prior_mean)
         self.prior_weight_sigma.fill_(self.prior_variance)      # "variance" is used as sigma_p, as in the reference
@@ -112,26 +114,48 @@ class FusedBayesLayer(BaseVariationalLayer_):
         segs = self._kl_segments()
         if torch.is_grad_enabled() and any(t.requires_grad for sg in segs for t in sg):
             from ..autograd import KLNormal
-            return KLNormal.apply((("layer", self._layer_id), kind), *[t for sg in segs for t in sg])
-        return _lib.kl_normal(segs, layer_ids=[0] * len(segs), owner=("layer", self._layer_id), laplace=kind == "laplace")
+            return KLNormal.apply((("layer", self._ws_id), kind), *[t for sg in segs for t in sg])
+        return _lib.kl_normal(segs, layer_ids=[0] * len(segs), owner=("layer", self._ws_id), laplace=kind == "laplace")
 
     # ------------------------------------------------------------------ forward
+    def _pack_source(self):
+        """(mu, rho) in the [Co][Ci/g][taps...] layout the pack is built from (the family layers re-arrange theirs)."""
+        return self._w("mu").detach(), self._w("rho").detach()
+
+    def _pack_segment(self):
+        """This layer's entry of a bt_pack_sync call. The pack lives in persistent buffers (a captured graph bakes their
+        addresses in; they are re-allocated -- and rebuilt unconditionally -- only when a parameter TENSOR is replaced:
+        ``.to(device)``, a new nn.Parameter)."""
+        mu, rho = self._w("mu").detach(), self._w("rho").detach()
+        smu, srho = self._pack_source()
+        Co, Ci = smu.shape[0], smu.shape[1]
+        taps = 1
+        for d in smu.shape[2:]:
+            taps *= d
+        key = (mu.data_ptr(), rho.data_ptr(), tuple(smu.shape), mu.device)
+        force = self._pack_force
+        if self._pack is None or self._pack[0] != key:
+            self._pack = (key,) + F.pack_buffers(Co, Ci, taps, mu.device)
+            force = True
+        self._pack_force = False
+        same = smu.data_ptr() == mu.data_ptr() and srho.data_ptr() == rho.data_ptr()
+        return dict(mu=mu, rho=rho, src_mu=None if same else smu.contiguous(), src_rho=None if same else srho.contiguous(), mu_packed=self._pack[1],
+                    sigma_packed=self._pack[2], state=self._pack[3], Co=Co, Ci=Ci, taps=taps, force=force)
+
     def _packed(self):
-        """(mu_packed, sigma_packed): tap-major copies of (mu, softplus(rho)) for the fast kernel. Cached only for
-        inference (module in eval mode or grad disabled), keyed on the parameters' versions and addresses (in-place
-        autograd-visible updates bump ._version; a new tensor changes data_ptr); writes through ``.data`` bypass the
-        version counter -- see invalidate_pack(). While training with grad enabled the pack is rebuilt on every call
-        (one cheap kernel), so an optimizer step or a ``.data`` update can never leave the forward on stale weights."""
-        mu, rho = self._w("mu"), self._w("rho")
-        if self.training and torch.is_grad_enabled():
-            self._sigma_cache = None
-            return F.pack_params(mu.detach(), rho.detach())
-        key = (mu._version, mu.data_ptr(), rho._version, rho.data_ptr())
-        c = self._sigma_cache
-        if c is None or c[0] != key:
-            c = (key, F.pack_params(mu.detach(), rho.detach()))
-            self._sigma_cache = c
-        return c[1]
+        """(mu_packed, sigma_packed): tap-major copies of (mu, softplus(rho)) for the fast kernels, verified against the
+        parameters on the device before EVERY forward (bt_pack_sync: a fingerprint sweep of (mu, rho) + a rebuild of the
+        packs that differ, both in the stream). ``mc_forward`` / ``McGraph`` / ``TrainGraph`` run the check once per model
+        (``mc.sync_model_packs``); a layer called on its own checks itself."""
+        ctx = mc.current()
+        if ctx is not None and id(self) in ctx.synced and self._pack is not None and not self._pack_force:
+            return self._pack[1], self._pack[2]
+        F.pack_sync([self._pack_segment()], owner=("layer", self._ws_id))
+        return self._pack[1], self._pack[2]
+
+    def pack_rebuilds(self):
+        """How many times this layer's pack has been (re)built -- a device counter kept by bt_pack_sync (synchronises)."""
+        return 0 if self._pack is None else int(self._pack[3][3])
 
     def _conv_desc(self):
         if getattr(self, "_one_d", False):       # Conv1d: a 1 x k kernel over a 1 x L image
@@ -214,21 +238,22 @@ class FusedBayesLayer(BaseVariationalLayer_):
             kl = None
             if want_kl:
                 flat = [t for sg in self._kl_segments() for t in sg]
-                kl = KLNormal.apply((("layer", self._layer_id), kind), *flat)
+                kl = KLNormal.apply((("layer", self._ws_id), kind), *flat)
         else:
             priors = (self.prior_weight_mu, self.prior_weight_sigma, self.prior_bias_mu, self.prior_bias_sigma) if want_kl else None
             out, kl = F.fused_forward(x, mu_t, rho_t, self.mu_bias, self.rho_bias, flip=self._flip, conv=conv,
                                       S=S, shared_x=shared, priors=priors, eps_w=draw.get("eps_w"), eps_b=draw.get("eps_b"),
                                       sign_in=draw.get("sign_in"), sign_out=draw.get("sign_out"), seed=seed, call=call,
                                       layer_id=self._layer_id, sample0=sample0, call_base=call_base, want_kl=want_kl,
-                                      workspace_owner=("layer", self._layer_id), post_scale=self.post_scale, post_shift=self.post_shift,
+                                      workspace_owner=("layer", self._ws_id), post_scale=self.post_scale, post_shift=self.post_shift,
                                       residual=residual, relu=self.post_relu, pool=self.post_pool, packed=self._packed(), prior_type=kind)
         conv_shape = tuple(out.shape[1:])     # shape of one sample's contraction output (sign_out's shape): before any fused pooling
         if self.post_pool and conv is not None:
             conv_shape = (out.shape[1],) + F.conv_out_hw(x.shape[2], x.shape[3], mu_t.shape[2], mu_t.shape[3], *conv["stride"],
                                                          *conv["padding"], *conv["dilation"])
         self._last = dict(draw=draw or None, rng=(seed, call_base, call, self._layer_id, sample0), S=S,
-                          kernel=_lib.lib().bt_last_kernel_name().decode(),
+                          kernel=_lib.lib().bt_last_kernel_name().decode(), launch=_lib.last_launch_info(),
+                          shared_x=shared, residual=residual is not None, fused_kl=bool(want_kl and not needs_grad),
                           x_shape=(B,) + tuple(x.shape[1:]), out_shape=(B,) + conv_shape)
         if lead is not None:
             out = out.reshape(lead + (self.out_features,))

@@ -23,6 +23,7 @@ class McContext:
         self.collect_kl = collect_kl
         self.kls = []            # per-layer 0-dim KL tensors in execution order (collect_kl)
         self.call_base = call_base  # device uint32 word (graph replay) or None
+        self.synced = set()      # id() of the layers whose packs sync_model_packs has verified inside this context
 
 
 def current():
@@ -40,6 +41,23 @@ def mc_samples(S, batch, sample0=0, collect_kl=False, call_base=None):
         _tls.ctx = prev
 
 
+def sync_model_packs(model, ctx=None, force=False):
+    """Verify -- on the device, in the current stream -- that every Bayesian layer's packed (mu, softplus(rho)) copy still matches
+    its parameters, and rebuild the ones that do not (bt_pack_sync: one fingerprint launch + one conditional pack launch per 64
+    layers and device, instead of two launches per layer). Inside ``ctx`` the layers then skip their own check."""
+    from . import functional as F
+    by_dev = {}
+    for m in model.modules():
+        if hasattr(m, "_pack_segment") and m._w("mu").is_cuda:
+            if force:
+                m._pack_force = True
+            by_dev.setdefault(m._w("mu").device, []).append(m)
+    for dev, layers in by_dev.items():
+        F.pack_sync([m._pack_segment() for m in layers], owner=("model", id(model)))
+        if ctx is not None:
+            ctx.synced.update(id(m) for m in layers)
+
+
 def mc_forward(model, x, S, sample0=0, with_kl=True):
     """S MC samples of ``model`` on batch ``x`` -> (logits[S, B, ...], kl or None).
 
@@ -48,6 +66,7 @@ def mc_forward(model, x, S, sample0=0, with_kl=True):
     forward kernels (fused) when ``with_kl``."""
     B = x.shape[0]
     with torch.no_grad(), mc_samples(S, B, sample0, collect_kl=with_kl) as ctx:
+        sync_model_packs(model, ctx)
         out = model(x)
     if isinstance(out, tuple):   # native Bayesian models return (logits, kl_sum)
         out = out[0]
@@ -64,11 +83,14 @@ class McGraph:
     bt_rng.call_base_dev) to its baked-in ``call`` coordinate, and ``replay()`` sets that word so that the replay draws at the
     host counter's current position and then advances the host counter by the number of layer calls -- a replay consumes
     exactly the coordinates an eager ``mc_forward`` at that moment would have, so eager calls, replays and several graphs
-    can interleave without ever reusing a draw.  Parameters are baked in by address (including the layers' packed copies):
-    re-capture after a parameter update.
+    can interleave without ever reusing a draw.  Parameters are baked in by address; the layers' packed copies live in
+    persistent buffers and the captured step begins with the device-side pack check (``sync_model_packs``), so a replay
+    FOLLOWS parameter updates made in place (optimizer steps, ``.data`` writes, load_state_dict).  Re-capture only when a
+    parameter tensor is replaced (``.to()``, a new nn.Parameter).  ``force_pack``: rebuild every pack on every replay (the
+    benchmark's with-rebuild figure).
     ("capturing the whole model per sample in a HIP graph".)"""
 
-    def __init__(self, model, x, S, sample0=0, with_kl=True, epilogue=True):
+    def __init__(self, model, x, S, sample0=0, with_kl=True, epilogue=True, force_pack=False):
         from . import functional as F, rng
         self.S, self.B = int(S), x.shape[0]
         self.x = x.clone()
@@ -77,6 +99,7 @@ class McGraph:
         def run():
             B = self.B
             with torch.no_grad(), mc_samples(self.S, B, sample0, collect_kl=with_kl, call_base=self.call_base) as ctx:
+                sync_model_packs(model, ctx, force=force_pack)
                 out = model(self.x)
             out = out[0] if isinstance(out, tuple) else out
             logits = out.reshape(self.S, B, *out.shape[1:])
@@ -93,6 +116,7 @@ class McGraph:
             self.calls_per_run = rng.peek_call() - c0
         torch.cuda.current_stream().wait_stream(side)
         self.call0 = rng.peek_call()           # the call coordinate baked into the first captured layer
+        self._packs = [m._pack for m in model.modules() if hasattr(m, "_pack_segment")]   # the buffers whose addresses the graph bakes in
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.logits, self.kl, self.packed = run()
@@ -129,7 +153,8 @@ class TrainGraph:
 
         def run():
             optimizer.zero_grad(set_to_none=True)
-            with mc_samples(1, B, 0, collect_kl=False, call_base=self.call_base):
+            with mc_samples(1, B, 0, collect_kl=False, call_base=self.call_base) as ctx:
+                sync_model_packs(model, ctx)     # the optimizer step of the previous replay changed every parameter: one check + rebuild per model
                 out = model(self.x)
             out = out[0] if isinstance(out, tuple) else out
             loss = loss_fn(model, out, self.y)

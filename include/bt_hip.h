@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BT_VERSION 201
+#define BT_VERSION 300
 #define BT_WORKSPACE_BYTES 65536
 
 #define BT_OK 0
@@ -125,6 +125,9 @@ const char *bt_last_error_string(void);
 /* Diagnostic: the kernel instance (template name and tile) the calling thread's last fused-forward launch selected --
  * lets a benchmark attribute per-launch times to kernel instances the way rocprofv3's kernel trace does. */
 const char *bt_last_kernel_name(void);
+/* ... and that launch's tile geometry, for a benchmark's roofline model: out[0..n) <- {workgroups, m_tiles, n_tiles, S, images per
+ * tile, output rows per tile, output columns per tile, pixel_major, row_tiles, kl_slices, groups, n_bt, n_rt, n_ct, fused KL, 0}. */
+int bt_last_launch_info(int64_t *out, int32_t n);
 
 /* a5: LinearReparameterization.forward  (layers/variational_layers/linear_variational.py:160-181)
  *   out[s][b][o] = sum_k x_s[b][k] * (mu_w + log1p(exp(rho_w)) * eps_w[s])[o][k] + (mu_b + log1p(exp(rho_b)) * eps_b[s])[o]
@@ -178,6 +181,27 @@ int bt_kl_normal(int32_t n_segments, const float *const *mu, const float *const 
  * the kernels' own softplus, so a forward with or without the packed copies is bit-identical. */
 int bt_pack_params(const float *mu_w, const float *rho_w, int64_t Co, int64_t Ci, int64_t taps,
                    float *mu_packed, float *sigma_packed, bt_stream_t stream);
+
+/* Keeps the packed copies of up to BT_PACK_MAX_SEGMENTS layers in step with their parameters, checked ON THE DEVICE in the
+ * stream (two launches, no host synchronisation, graph-capturable): a 64-bit fingerprint of every layer's natural-layout
+ * (mu_w, rho_w) -- the wrapping sum of a 64-bit mix of (element index, mu bits, rho bits): order-independent, so deterministic --
+ * is compared with the one stored in `state` when the pack was last built, and exactly the layers that differ (or carry
+ * `force`) are re-packed in place. The reference's own code writes parameters through `.data` (models/dnn_to_bnn.py:65-71,95-101,
+ * utils/util.py:102-117 in MOPED()), which no host-side version counter can see: with this call in front of the forward a
+ * stale pack cannot be read. Segment array: HOST. */
+#define BT_PACK_MAX_SEGMENTS 64
+typedef struct bt_pack_seg {
+  const float *mu_w, *rho_w;       /* the parameters, natural layout: what the fingerprint covers */
+  const float *src_mu, *src_rho;   /* optional: an exact re-arrangement of them to pack from ([Co][Ci][taps]; the transposed-convolution
+                                      layers pack their channel-transposed, flipped kernel); both NULL = mu_w / rho_w */
+  float *mu_packed, *sigma_packed; /* [Co][taps][Ci4], rewritten in place when the fingerprint differs */
+  uint64_t *state;                 /* DEVICE, 4 words owned by the layer, zero-filled once: accumulator (left zero), fingerprint
+                                      of the packed copy, dirty flag of the last call, number of rebuilds so far */
+  int64_t Co, Ci, taps;            /* geometry of the pack source */
+  int32_t force;                   /* rebuild whatever the fingerprint says (first use of fresh buffers) */
+  int32_t reserved;
+} bt_pack_seg;
+int bt_pack_sync(int32_t n_segments, const bt_pack_seg *segs, void *workspace, size_t workspace_bytes, bt_stream_t stream);
 
 /* The on-chip draws, materialised (test / replay hook: the fused kernels never call these).
  * They emit exactly the streams the fused kernels consume for (rng, tensor_id):

@@ -158,7 +158,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), name
     L = _lib.lib()
-    assert L.bt_version() == 201
+    assert L.bt_version() == 300
     # host-only entry: Philox4x32-10 known answers (Random123 kat_vectors)
     def philox(ctr, key):
         c = (ctypes.c_uint32 * 4)(*ctr)
@@ -176,6 +176,7 @@ def test_struct_layouts_match_header():
     from bayesian_torch_amd import _lib
     assert ctypes.sizeof(_lib.bt_rng) == 32 and ctypes.sizeof(_lib.bt_params) == 88
     assert ctypes.sizeof(_lib.bt_draws) == 64 and ctypes.sizeof(_lib.bt_conv2d_geom) == 56 and ctypes.sizeof(_lib.bt_epilogue) == 40
+    assert ctypes.sizeof(_lib.bt_pack_seg) == 88
 
 
 def test_fold_batchnorm_host_logic():
@@ -223,3 +224,17 @@ def test_moped_from_checkpoint(tmp_path):
     MOPED(bnn, det2, ck, 0.3)
     assert torch.equal(bnn[0].mu_kernel.data, det[0].weight.data) and torch.equal(bnn[0].prior_weight_mu, det[0].weight.data)
     assert torch.allclose(bnn[3].rho_weight.data, get_rho(det[3].weight.data, 0.3)) and torch.equal(bnn[3].mu_bias.data, det[3].bias.data)
+
+
+def test_two_models_do_not_share_workspaces():
+    """layer ids are positional (RNG coordinate) but the KL / pack workspaces are keyed per live layer object."""
+    from bayesian_torch_amd.harness import resnet as H
+    from bayesian_torch_amd.models.dnn_to_bnn import dnn_to_bnn
+    nets = []
+    for _ in range(2):
+        net = H.resnet18(10, 8)
+        dnn_to_bnn(net, PRIOR)
+        nets.append(net)
+    a, b = ([m for _, m in H.bayes_layers(n)] for n in nets)
+    assert [m._layer_id for m in a] == [m._layer_id for m in b]
+    assert not ({m._ws_id for m in a} & {m._ws_id for m in b})

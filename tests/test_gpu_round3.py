@@ -1,0 +1,266 @@
+"""GPU parity added in round 3: the device-side pack check (a stale pack cannot be read, whatever way the parameters were written),
+graph replays that follow parameter updates, and the rest of the layer family inside mc_samples."""
+import pytest
+import torch
+
+from conftest import assert_close, golden_names, layer_tensors, load_golden
+
+pytestmark = pytest.mark.gpu
+PRIOR = {"prior_mu": 0.0, "prior_sigma": 1.0, "posterior_mu_init": 0.0, "posterior_rho_init": -3.0, "moped_enable": False, "moped_delta": 0.5}
+RTOL, ATOL = 1e-4, 1e-5
+CD = dict(stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1)
+
+
+def _check_conv(conv, x, what):
+    from oracle import bt_oracle as O
+    with torch.no_grad():
+        out = conv(x, return_kl=False)
+    d = conv.materialize_last_draw()
+    ref = O.reparam_fwd_ref(x.cpu(), conv.mu_kernel.detach().cpu(), conv.rho_kernel.detach().cpu(), d["eps_w"][0].cpu(), conv=CD)
+    assert_close(out.cpu(), ref, RTOL, ATOL, what)
+
+
+def test_data_writes_cannot_leave_a_stale_pack():
+    """VERDICT r2 item 8. The reference's own idioms write parameters through ``.data`` (models/dnn_to_bnn.py:95-101
+    ``mu_kernel.data.copy_``; utils/util.py:102-117 ``mu_kernel.data = w``), which no version counter sees. Every forward checks a
+    device-side fingerprint of (mu, rho) against its pack's (bt_pack_sync), so none of these needs invalidate_pack() -- and an
+    unchanged layer is not re-packed."""
+    from bayesian_torch_amd import rng
+    import bayesian_torch_amd.layers as L
+    torch.manual_seed(0)
+    conv = L.Conv2dReparameterization(8, 16, 3, padding=1, bias=False).cuda().eval()
+    x = torch.randn(4, 8, 6, 6).cuda()
+    rng.set_mode("philox")
+    _check_conv(conv, x, "first forward")
+    n0 = conv.pack_rebuilds()
+    assert n0 == 1
+    _check_conv(conv, x, "second forward, same parameters")
+    assert conv.pack_rebuilds() == n0, "an unchanged layer must not be re-packed"
+    conv.mu_kernel.data.copy_(torch.randn_like(conv.mu_kernel) * 0.2)                 # dnn_to_bnn.py:95-101
+    _check_conv(conv, x, "after mu.data.copy_ (no invalidate_pack)")
+    conv.rho_kernel.data.copy_(torch.randn_like(conv.rho_kernel) * 0.1 - 2.0)
+    _check_conv(conv, x, "after rho.data.copy_")
+    assert conv.pack_rebuilds() == n0 + 2
+    conv.mu_kernel.data.mul_(-1.5)                                                   # in place through .data
+    _check_conv(conv, x, "after mu.data.mul_")
+    conv.mu_kernel.data[3, 2, 1, 1] += 1e-3                                          # ONE element, one ulp-scale nudge
+    _check_conv(conv, x, "after a single-element write")
+    assert conv.pack_rebuilds() == n0 + 4
+    conv.mu_kernel.data = torch.randn_like(conv.mu_kernel) * 0.3                      # util.py:102-117 (MOPED): a new storage
+    conv.rho_kernel.data = torch.full_like(conv.rho_kernel, -2.5)
+    _check_conv(conv, x, "after .data = new tensor")
+    with torch.no_grad():
+        for p in conv.parameters():
+            p.add_(0.01)                                                             # what an optimizer step does
+    _check_conv(conv, x, "after an in-place update under no_grad")
+    sd = {k: v.clone() * 0.5 for k, v in conv.state_dict().items()}
+    conv.load_state_dict(sd)
+    _check_conv(conv, x, "after load_state_dict")
+    # the restore case: parameters go back to an OLDER value -- the pack must follow (a fingerprint kept from that older state must not
+    # be trusted over a pack built later)
+    old = conv.mu_kernel.detach().clone()
+    conv.mu_kernel.data.add_(1.0)
+    _check_conv(conv, x, "moved away")
+    conv.mu_kernel.data.copy_(old)
+    _check_conv(conv, x, "restored to the older value")
+    conv.train()
+    out = conv(x, return_kl=False)                                                   # training path (autograd bridge) reads the same pack
+    d = conv.materialize_last_draw()
+    from oracle import bt_oracle as O
+    ref = O.reparam_fwd_ref(x.cpu(), conv.mu_kernel.detach().cpu(), conv.rho_kernel.detach().cpu(), d["eps_w"][0].cpu(), conv=CD)
+    assert_close(out.detach().cpu(), ref, RTOL, ATOL, "training-mode forward")
+
+
+def test_model_level_pack_sync_and_graph_replay_follow_updates():
+    """mc_forward checks all layers in one bt_pack_sync; a captured McGraph contains that check, so a replay follows in-place
+    parameter updates (it used to replay against dropped pack storage). Compared with an eager mc_forward at the same
+    RNG coordinates after every kind of update."""
+    from bayesian_torch_amd import rng
+    from bayesian_torch_amd.harness import resnet as H
+    from bayesian_torch_amd.mc import McGraph, mc_forward
+    from bayesian_torch_amd.models.dnn_to_bnn import dnn_to_bnn
+    torch.manual_seed(1)
+    net = H.resnet18(10, 16)
+    dnn_to_bnn(net, dict(PRIOR, type="Reparameterization"))
+    H.fill_bayes_params(net, 3)
+    net = net.cuda().eval()
+    x = torch.randn(8, 3, 32, 32).cuda()
+    rng.set_mode("philox")
+    rng.manual_seed(11)
+    S = 3
+    g = McGraph(net, x, S, with_kl=True, epilogue=False)
+    layers = [m for _, m in H.bayes_layers(net)]
+
+    def both(what):
+        c = rng.peek_call()
+        lg, kg, _ = g.replay()
+        lg, kg = lg.clone(), kg.clone()
+        rng.set_call(c)
+        le, ke = mc_forward(net, x, S)
+        assert torch.equal(lg, le), what + ": graph replay != eager forward at the same coordinates"
+        assert torch.equal(kg, ke), what + ": kl"
+        return lg
+    a = both("fresh")
+    r0 = [m.pack_rebuilds() for m in layers]
+    b = both("again")
+    assert [m.pack_rebuilds() for m in layers] == r0 and not torch.equal(a, b)
+    layers[5].mu_kernel.data.mul_(1.25)                       # .data write on ONE layer
+    both("after a .data write")
+    r1 = [m.pack_rebuilds() for m in layers]
+    assert r1[5] == r0[5] + 1 and r1[:5] == r0[:5] and r1[6:] == r0[6:], "exactly the changed layer is re-packed"
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(0.9)                                       # an optimizer-style update of everything
+    both("after an in-place update of every parameter")
+    sd = {k: (v * 1.1 if v.is_floating_point() else v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    both("after load_state_dict")
+
+
+def test_family_layers_inside_mc_samples():
+    """Conv3d / ConvTranspose layers under mc_samples(S > 1) with a shared [B, ...] input (the first layer of a
+    model under mc_forward) and with a stacked [S*B, ...] one -- against S separate calls on the same injected draws."""
+    import bayesian_torch_amd.layers as L
+    from bayesian_torch_amd.mc import mc_samples
+    torch.manual_seed(0)
+    S, B = 2, 3
+    cases = [
+        (L.Conv3dReparameterization(2, 4, 3, 0, 1, 0, -3.0, padding=1), (2, 5, 6, 6)),
+        (L.Conv3dFlipout(2, 4, (2, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1)), (2, 4, 7, 7)),
+        (L.ConvTranspose2dReparameterization(4, 6, 3, stride=2, padding=1, output_padding=1), (4, 5, 5)),
+        (L.ConvTranspose1dFlipout(4, 2, 3, stride=2), (4, 9)),
+        (L.ConvTranspose3dReparameterization(2, 3, 2, stride=2), (2, 3, 4, 4)),
+    ]
+    for layer, xs in cases:
+        layer = layer.cuda().eval()
+        name = type(layer).__name__
+        w = layer.mu_kernel
+        xb = torch.randn(B, *xs).cuda()
+        xst = torch.randn(S * B, *xs).cuda()
+        for shared in (True, False):
+            x = xb if shared else xst
+            with torch.no_grad():
+                probe = layer(x[:B], return_kl=False)
+            draw = dict(eps_w=torch.randn(S, *w.shape).cuda(), eps_b=torch.randn(S, layer.out_channels).cuda())
+            if layer._flip:
+                draw["sign_in"] = torch.randn(S, B, *xs).cuda().sign()
+                draw["sign_out"] = torch.randn(S, *probe.shape).cuda().sign()
+            layer.inject_draw = draw
+            with torch.no_grad(), mc_samples(S, B):
+                out = layer(x, return_kl=False)
+            assert out.shape == (S * B,) + tuple(probe.shape[1:]), (name, shared, out.shape)
+            for s in range(S):
+                layer.inject_draw = {k: v[s:s + 1] for k, v in draw.items()}
+                with torch.no_grad():
+                    one = layer(x if shared else x[s * B:(s + 1) * B], return_kl=False)
+                assert_close(out[s * B:(s + 1) * B], one, 1e-5, 1e-6, f"{name} shared={shared} sample {s}")
+            layer.inject_draw = None
+            with torch.no_grad(), mc_samples(S, B):
+                o2 = layer(x, return_kl=False)                  # on-chip draws under MC batching: shape, finite, samples differ
+            assert o2.shape == out.shape and torch.isfinite(o2).all()
+            d = layer.materialize_last_draw()                  # (_last is populated: ADVICE r2)
+            assert d["eps_w"].shape == (S,) + tuple(w.shape) and not torch.equal(d["eps_w"][0], d["eps_w"][1])
+
+
+def test_family_on_chip_draw_replays_through_the_injection_path():
+    """materialize_last_draw() of a family layer returns eps in the REFERENCE's kernel layout: feeding it back through inject_draw
+    reproduces the on-chip forward bit for bit (Reparameterization: the draw is eps alone)."""
+    import bayesian_torch_amd.layers as L
+    from bayesian_torch_amd import rng
+    torch.manual_seed(0)
+    rng.set_mode("philox")
+    for layer, xs in [(L.ConvTranspose2dReparameterization(4, 6, 3, stride=2, padding=1, groups=2), (2, 4, 5, 5)),
+                      (L.Conv3dReparameterization(2, 4, 3, 0, 1, 0, -3.0, padding=1), (2, 2, 4, 6, 6))]:
+        layer = layer.cuda().eval()
+        x = torch.randn(*xs).cuda()
+        with torch.no_grad():
+            a = layer(x, return_kl=False)
+        d = layer.materialize_last_draw()
+        layer.inject_draw = dict(eps_w=d["eps_w"], eps_b=d["eps_b"])
+        with torch.no_grad():
+            b = layer(x, return_kl=False)
+        assert_close(a, b, 1e-6, 1e-7, type(layer).__name__)
+
+
+# ------------------------------------------------------------------------------------------------ the direct 1x1 kernel
+# Ci, Co, groups, H, W, B, S, bias, extras (scale/shift, residual, relu)
+DIRECT = {
+    "K=64 -> 256, 24x24, b16 (ResNet50 layer1 conv3 shape, residual + BN + ReLU)": (64, 256, 1, 24, 24, 16, 2, False, True),
+    "K=256 -> 64, 24x24, b16 (reducing 1x1)": (256, 64, 1, 24, 24, 16, 2, True, False),
+    "K=128 -> 512, 14x14 (H*W % 4 == 0, W % 4 != 0), b48": (128, 512, 1, 14, 14, 48, 2, False, True),
+    "K=256 -> 96 (partial channel tile), 7x7 (odd plane), b200, M % 64 != 0": (256, 96, 1, 7, 7, 200, 1, True, True),
+    "groups 2: 128 -> 160 (80 per group: 2 tiles, the second partial), 20x20, b24": (128, 160, 2, 20, 20, 24, 2, True, False),
+    "K=192, 33x31, b9 (M = 9207: ragged last sub-tile), S=3": (192, 64, 1, 33, 31, 9, 3, False, True),
+}
+
+
+@pytest.mark.parametrize("name", list(DIRECT))
+def test_direct_1x1_kernel_vs_general_kernel_and_c_oracle(name):
+    """bt_fused_split_direct.h (persistent workgroups, sampled weights resident in LDS, x straight into registers) against the
+    general split kernel on the same RNG coordinates -- same canonical K order and term order: bit for bit -- and against the
+    plain-C oracle (fp64 accumulation) on the materialised draws at the unchanged tolerance; KL against the standalone kernel."""
+    from oracle import c_oracle as CO
+    from bayesian_torch_amd import _lib
+    from bayesian_torch_amd import functional as F
+    Ci, Co, grp, H, W, B, S, bias, extras = DIRECT[name]
+    g = torch.Generator().manual_seed(abs(hash(name)) % (1 << 31))
+    dev = torch.device("cuda")
+    mu = (torch.randn(Co, Ci // grp, 1, 1, generator=g) * 0.1).to(dev)
+    rho = (torch.randn(Co, Ci // grp, 1, 1, generator=g) * 0.1 - 3).to(dev)
+    mb = (torch.randn(Co, generator=g) * 0.1).to(dev) if bias else None
+    rb = (torch.randn(Co, generator=g) * 0.1 - 3).to(dev) if bias else None
+    x = torch.randn(S * B, Ci, H, W, generator=g).to(dev)
+    conv = dict(stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=grp)
+    kw = {}
+    if extras:
+        kw = dict(post_scale=(torch.rand(Co, generator=g) + 0.5).to(dev), post_shift=(torch.randn(Co, generator=g) * 0.1).to(dev),
+                  residual=torch.randn(S * B, Co, H, W, generator=g).to(dev), relu=True)
+    pri = (torch.zeros_like(mu), torch.ones_like(mu), None if mb is None else torch.zeros_like(mb), None if mb is None else torch.ones_like(mb))
+    L = _lib.lib()
+
+    def run(direct):
+        L.bt_debug_disable_direct(0 if direct else 1)
+        try:
+            out, kl = F.fused_forward(x, mu, rho, mb, rb, conv=conv, S=S, shared_x=False, seed=77, call=2, layer_id=9, sample0=5, packed=F.pack_params(mu, rho),
+                                      priors=pri, want_kl=True, workspace_owner="t_direct", **kw)
+            return out, kl, L.bt_last_kernel_name().decode()
+        finally:
+            L.bt_debug_disable_direct(0)
+    out, kl, kn = run(True)
+    assert "fused_split_direct_kernel" in kn, kn
+    ref, klr, kn0 = run(False)
+    assert "direct" not in kn0 and "bf16x3" in kn0, kn0
+    assert torch.equal(out, ref), f"{name}: direct kernel differs from {kn0}: max abs {float((out - ref).abs().max()):.3e}"
+    assert_close(kl, klr, 1e-6, 0, name + ".kl")
+    segs = [(mu, rho, pri[0], pri[1])] + ([(mb, rb, pri[2], pri[3])] if bias else [])
+    assert_close(kl, _lib.kl_normal(segs, layer_ids=[0] * len(segs), owner="t_direct_kl"), 1e-6, 0, name + ".kl vs standalone")
+    # the C oracle on the materialised draws, two samples' worth of the first images (bounded CPU time)
+    eps_w = F.rng_fill_normal(77, 2, 9, 5, 0, S, mu.shape, dev).cpu()
+    eps_b = F.rng_fill_normal(77, 2, 9, 5, 1, S, (Co,), dev).cpu() if bias else None
+    nb = min(B, 8)
+    o = out.reshape((S, B) + tuple(out.shape[1:]))
+    for s in range(S):
+        want = CO.reparam_fwd(x[s * B:s * B + nb].cpu(), mu.cpu(), rho.cpu(), eps_w[s], None if mb is None else mb.cpu(), None if rb is None else rb.cpu(),
+                              None if eps_b is None else eps_b[s], conv)
+        if extras:
+            want = torch.relu(want * kw["post_scale"].cpu().view(1, -1, 1, 1) + kw["post_shift"].cpu().view(1, -1, 1, 1) + kw["residual"][s * B:s * B + nb].cpu())
+        assert_close(o[s, :nb].cpu(), want, RTOL, ATOL, f"{name}[s={s}] vs C oracle")
+
+
+def test_direct_kernel_shared_x_and_launch_split_independence():
+    """Same global sample ids in one launch or several, shared or stacked x: bit-identical (the direct kernel's eligibility is
+    geometric, never a matter of S)."""
+    from bayesian_torch_amd import _lib
+    from bayesian_torch_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    dev = torch.device("cuda")
+    mu, rho = (torch.randn(128, 64, 1, 1, generator=g) * 0.1).to(dev), (torch.randn(128, 64, 1, 1, generator=g) * 0.1 - 3).to(dev)
+    x1 = torch.randn(32, 64, 20, 20, generator=g).to(dev)
+    conv = dict(stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1)
+    pk = F.pack_params(mu, rho)
+    run = lambda x, S, s0, shared: F.fused_forward(x, mu, rho, conv=conv, S=S, shared_x=shared, seed=3, call=1, layer_id=4, sample0=s0, packed=pk)[0]
+    full = run(x1, 4, 10, True)
+    assert "direct" in _lib.lib().bt_last_kernel_name().decode()
+    parts = torch.cat([run(x1, 1, 10 + s, True) for s in range(4)])
+    assert torch.equal(parts, full)
+    assert torch.equal(run(torch.cat([x1] * 4), 4, 10, False), full)
