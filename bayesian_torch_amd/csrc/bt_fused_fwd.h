@@ -72,6 +72,7 @@ struct FwdArgs {
   uint32_t inv_m_tiles, inv_S, inv_n_tiles, inv_n_bt, inv_n_ct, inv_rw, inv_wt, inv_kw;
   int x_flat;  // split flavour, XM 3: the patch is the whole input plane -- fetch it as one row of H*W pixels
   int row_taps;  // split flavour: tiles = t_NI images x ONE output row; the active taps are those of the tile's row (2-row maps)
+  int d_tap;     // direct flavour: the ONE tap of the kernel window that meets data (0 for 1x1 kernels; the centre of a padded window over a 1x1 image)
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2). Give every XCD a CONTIGUOUS range of

@@ -125,8 +125,21 @@ static int launch_quad(FwdArgs& a, int mode, hipStream_t stream) {
 static std::atomic<int> g_direct_off{0};
 static int launch_direct(FwdArgs& a, hipStream_t stream) {
   if (g_direct_off.load(std::memory_order_relaxed)) return 1;
-  if (a.KH != 1 || a.KW != 1 || a.SH != 1 || a.SW != 1 || a.PH || a.PW || a.ep_pool) return 1;
-  if ((a.Cig & 63) || a.Cig > kDirectMaxK || a.M < 8192) return 1;
+  if (a.ep_pool) return 1;
+  // a 1x1 kernel without padding (any stride), or any window over a 1x1 image whose ONE live tap sits on the pixel (ResNet18 / CIFAR
+  // layer4: 3x3, padding 1, 1x1 maps -- the centre tap; Linear layers are 1x1 kernels over 1x1 images)
+  if (a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0) {
+    a.d_tap = 0;
+  } else if (a.H == 1 && a.W == 1 && a.Ho == 1 && a.Wo == 1 && a.PH % a.DH == 0 && a.PW % a.DW == 0 && a.PH / a.DH < a.KH && a.PW / a.DW < a.KW) {
+    a.d_tap = (a.PH / a.DH) * a.KW + a.PW / a.DW;
+  } else {
+    return 1;
+  }
+  const bool resident = a.Cig <= kDirectMaxK;
+  // K > 256 streams the weights in chunks that all 8 waves draw and meet at: it needs every wave to own pixels (>= 4096 per sample).
+  // CIFAR-sized layers with K = 512 (128 pixels per sample: 2 of 8 waves would multiply, on 2 of the 4 matrix pipes) measured
+  // 87 us against the general kernel's 57 (profiles/r03f_layers_cfg3.json): they stay there. K <= 256 wins at any size.
+  if ((a.Cig & 63) || (!resident && ((a.Cig % (16 * kDirectChunk)) || a.M < 4096)) || a.M < 64) return 1;
   a.n_tiles = (a.Cog + 63) / 64;
   const long long pairs = (long long)a.G * a.n_tiles * a.S;
   const int nsub = (a.M + 63) / 64;
@@ -134,8 +147,13 @@ static int launch_direct(FwdArgs& a, hipStream_t stream) {
   // is a quarter of a workgroup's work), each with at least 64 sub-tiles (8 per wave) to walk
   long long chunks = (1024 + pairs - 1) / pairs;
   if (chunks > nsub / 64) chunks = nsub / 64;
-  if (chunks < 1) chunks = 1;
-  const int spc = (int)((nsub + chunks - 1) / chunks);
+  if (chunks < 1) {   // few pixels (CIFAR-sized maps): down to one sub-tile per wave, as long as that still adds workgroups the chip has room for
+    chunks = (256 + pairs - 1) / pairs;
+    if (chunks > nsub / 8) chunks = nsub / 8;
+    if (chunks < 1) chunks = 1;
+  }
+  int spc = (int)((nsub + chunks - 1) / chunks);
+  if (!resident) spc = (spc + 7) & ~7;   // the 8 waves walk 512-pixel tiles together
   chunks = (nsub + spc - 1) / spc;
   const long long total = pairs * chunks;
   if (total <= 0 || total > 0x7FFFFFFFll) return 1;
@@ -143,19 +161,24 @@ static int launch_direct(FwdArgs& a, hipStream_t stream) {
   a.total_blocks = (int)total;
   a.kl_slices = total < 256 ? (int)total : 256;
   a.inv_n_tiles = inv_u32(a.n_tiles, total), a.inv_m_tiles = inv_u32(a.m_tiles, total), a.inv_S = inv_u32(a.S, total);
-  a.inv_rw = inv_u32(a.HW, (long long)a.M + 64);   // pixel index -> (image, position)
+  a.inv_rw = inv_u32(a.HoWo, (long long)a.M + 64 * 8 * 2);   // pixel index -> (image, output position)
+  a.inv_wt = inv_u32(a.Wo, a.HoWo);                          // output position -> (row, column): strided layers
   const int lds = direct_lds_bytes(a.Cig);
-  static bool flags[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return set_error(BT_ERR_HIP_BASE, "fused forward (split, direct): hipGetDevice failed");
-  if (!flags[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fused_split_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, direct_lds_bytes(kDirectMaxK)) != hipSuccess)
-      return set_error(BT_ERR_HIP_BASE, "fused forward (split, direct): cannot raise the dynamic LDS limit");
-    flags[dev] = true;
-  }
-  note_kernel("fused_split_direct_kernel<64,8x64,bf16x3,6 terms,resident W>");
-  hipLaunchKernelGGL(fused_split_direct_kernel, dim3((unsigned)a.total_blocks), dim3(kDirectThreads), lds, stream, a);
-  return check_launch("fused forward (split, direct)");
+  auto launch = [&](auto kern, const char* nm, bool* flags, int max_lds) -> int {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return set_error(BT_ERR_HIP_BASE, "fused forward (split, direct): hipGetDevice failed");
+    if (!flags[dev]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
+        return set_error(BT_ERR_HIP_BASE, "fused forward (split, direct): cannot raise the dynamic LDS limit");
+      flags[dev] = true;
+    }
+    note_kernel(nm);
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.total_blocks), dim3(kDirectThreads), lds, stream, a);
+    return check_launch("fused forward (split, direct)");
+  };
+  static bool fr[64] = {}, fs[64] = {};
+  if (resident) return launch(fused_split_direct_kernel<true>, "fused_split_direct_kernel<64,8x64,bf16x3,6 terms,resident W>", fr, direct_lds_bytes(kDirectMaxK));
+  return launch(fused_split_direct_kernel<false>, "fused_split_direct_kernel<64,8x64,bf16x3,6 terms,streamed W>", fs, direct_lds_bytes(kDirectMaxK + 1));
 }
 
 // Returns BT_OK when the launch was taken, 1 when this flavour does not apply (the caller runs the fp32 kernels), < 0 on error.

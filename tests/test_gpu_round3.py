@@ -183,8 +183,16 @@ def test_family_on_chip_draw_replays_through_the_injection_path():
 
 
 # ------------------------------------------------------------------------------------------------ the direct 1x1 kernel
-# Ci, Co, groups, H, W, B, S, bias, extras (scale/shift, residual, relu)
+# Ci, Co, groups, H, W, B, S, bias, extras (scale/shift, residual, relu) [, stride]
 DIRECT = {
+    "streamed W: K=512 -> 128, 14x14, b48 (reducing 1x1, 4 chunks)": (512, 128, 1, 14, 14, 48, 2, True, False),
+    "streamed W: K=1024 -> 96 (partial tile), 7x7, b180, ragged tiles": (1024, 96, 1, 7, 7, 180, 1, False, True),
+    "streamed W: K=2048 -> 64, 8x8, b130, S=2": (2048, 64, 1, 8, 8, 130, 2, False, False),
+    "downsample: K=256 -> 128, 1x1 stride 2, 28x28 -> 14x14, b48 (resident)": (256, 128, 1, 28, 28, 48, 2, False, True, 2),
+    "downsample: K=512 -> 192, 1x1 stride 2, 14x14 -> 7x7, b200 (streamed, odd plane)": (512, 192, 1, 14, 14, 200, 1, True, False, 2),
+    "stride (2, 1), groups 2: 128 -> 128, 12x10, b160": (128, 128, 2, 12, 10, 160, 2, True, True, (2, 1)),
+    "CIFAR downsample 64 -> 128, 1x1 s2, 8x8 -> 4x4, b128 (few pixels: one sub-tile per wave)": (64, 128, 1, 8, 8, 128, 2, False, True, 2),
+    "CIFAR downsample 256 -> 512, 1x1 s2, 2x2 -> 1x1, b128": (256, 512, 1, 2, 2, 128, 2, False, True, 2),
     "K=64 -> 256, 24x24, b16 (ResNet50 layer1 conv3 shape, residual + BN + ReLU)": (64, 256, 1, 24, 24, 16, 2, False, True),
     "K=256 -> 64, 24x24, b16 (reducing 1x1)": (256, 64, 1, 24, 24, 16, 2, True, False),
     "K=128 -> 512, 14x14 (H*W % 4 == 0, W % 4 != 0), b48": (128, 512, 1, 14, 14, 48, 2, False, True),
@@ -202,7 +210,10 @@ def test_direct_1x1_kernel_vs_general_kernel_and_c_oracle(name):
     from oracle import c_oracle as CO
     from bayesian_torch_amd import _lib
     from bayesian_torch_amd import functional as F
-    Ci, Co, grp, H, W, B, S, bias, extras = DIRECT[name]
+    Ci, Co, grp, H, W, B, S, bias, extras = DIRECT[name][:9]
+    stride = DIRECT[name][9] if len(DIRECT[name]) > 9 else 1
+    stride = tuple(stride) if isinstance(stride, tuple) else (stride, stride)
+    Ho, Wo = (H - 1) // stride[0] + 1, (W - 1) // stride[1] + 1
     g = torch.Generator().manual_seed(abs(hash(name)) % (1 << 31))
     dev = torch.device("cuda")
     mu = (torch.randn(Co, Ci // grp, 1, 1, generator=g) * 0.1).to(dev)
@@ -210,11 +221,11 @@ def test_direct_1x1_kernel_vs_general_kernel_and_c_oracle(name):
     mb = (torch.randn(Co, generator=g) * 0.1).to(dev) if bias else None
     rb = (torch.randn(Co, generator=g) * 0.1 - 3).to(dev) if bias else None
     x = torch.randn(S * B, Ci, H, W, generator=g).to(dev)
-    conv = dict(stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=grp)
+    conv = dict(stride=stride, padding=(0, 0), dilation=(1, 1), groups=grp)
     kw = {}
     if extras:
         kw = dict(post_scale=(torch.rand(Co, generator=g) + 0.5).to(dev), post_shift=(torch.randn(Co, generator=g) * 0.1).to(dev),
-                  residual=torch.randn(S * B, Co, H, W, generator=g).to(dev), relu=True)
+                  residual=torch.randn(S * B, Co, Ho, Wo, generator=g).to(dev), relu=True)
     pri = (torch.zeros_like(mu), torch.ones_like(mu), None if mb is None else torch.zeros_like(mb), None if mb is None else torch.ones_like(mb))
     L = _lib.lib()
 
@@ -227,7 +238,7 @@ def test_direct_1x1_kernel_vs_general_kernel_and_c_oracle(name):
         finally:
             L.bt_debug_disable_direct(0)
     out, kl, kn = run(True)
-    assert "fused_split_direct_kernel" in kn, kn
+    assert "fused_split_direct_kernel" in kn and ("streamed" in kn) == (Ci // grp > 256), kn
     ref, klr, kn0 = run(False)
     assert "direct" not in kn0 and "bf16x3" in kn0, kn0
     assert torch.equal(out, ref), f"{name}: direct kernel differs from {kn0}: max abs {float((out - ref).abs().max()):.3e}"
@@ -264,3 +275,52 @@ def test_direct_kernel_shared_x_and_launch_split_independence():
     parts = torch.cat([run(x1, 1, 10 + s, True) for s in range(4)])
     assert torch.equal(parts, full)
     assert torch.equal(run(torch.cat([x1] * 4), 4, 10, False), full)
+
+
+@pytest.mark.parametrize("case", ["3x3 pad 1 over 1x1 maps, 512 -> 128, b4200 (streamed)", "3x3 dilation 2 pad 2 over 1x1 maps, 256 -> 96, b100", "Linear 256 -> 10, b128", "Linear 1024 -> 200, b4100 (streamed)"])
+def test_direct_kernel_on_one_pixel_images_and_linear(case):
+    """A padded window over a 1x1 image has ONE live tap (ResNet18 / CIFAR layer4: the centre of the 3x3) and a Linear layer is a 1x1
+    kernel over a 1x1 image: both run on the direct kernel with the weights of that tap (tap-major draw index) and 16-byte channel
+    vectors for x -- bit-identical to the general kernel, and against the C oracle."""
+    from oracle import c_oracle as CO
+    from bayesian_torch_amd import _lib
+    from bayesian_torch_amd import functional as F
+    g = torch.Generator().manual_seed(abs(hash(case)) % (1 << 31))
+    dev = torch.device("cuda")
+    S = 2
+    if case.startswith("Linear"):
+        In, Out, B = (256, 10, 128) if "256" in case else (1024, 200, 4100)
+        mu, rho = (torch.randn(Out, In, generator=g) * 0.1).to(dev), (torch.randn(Out, In, generator=g) * 0.1 - 3).to(dev)
+        x = torch.randn(S * B, In, generator=g).to(dev)
+        conv = None
+    else:
+        Ci, Co, B, dil = (512, 128, 4200, 1) if "512" in case else (256, 96, 100, 2)
+        mu, rho = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.1).to(dev), (torch.randn(Co, Ci, 3, 3, generator=g) * 0.1 - 3).to(dev)
+        x = torch.randn(S * B, Ci, 1, 1, generator=g).to(dev)
+        conv = dict(stride=(1, 1), padding=(dil, dil), dilation=(dil, dil), groups=1)
+    mb, rb = (torch.randn(mu.shape[0], generator=g) * 0.1).to(dev), (torch.randn(mu.shape[0], generator=g) * 0.1 - 3).to(dev)
+    pk = F.pack_params(mu, rho)
+    L = _lib.lib()
+
+    def run(direct):
+        L.bt_debug_disable_direct(0 if direct else 1)
+        try:
+            out, _ = F.fused_forward(x, mu, rho, mb, rb, conv=conv, S=S, shared_x=False, seed=9, call=4, layer_id=2, sample0=1, packed=pk, relu=True)
+            return out, L.bt_last_kernel_name().decode()
+        finally:
+            L.bt_debug_disable_direct(0)
+    out, kn = run(True)
+    assert "fused_split_direct_kernel" in kn and ("streamed" in kn) == ("streamed" in case), kn
+    ref, kn0 = run(False)
+    assert "direct" not in kn0, kn0
+    if "bf16x3" in kn0:     # the general SPLIT kernel: same K order, same terms
+        assert torch.equal(out, ref), f"{case}: direct kernel differs from {kn0}: max abs {float((out - ref).abs().max()):.3e}"
+    else:                   # (fewer than 112 columns run on the fp32-MFMA kernels when the direct kernel is off: same draws, fp32 rounding apart)
+        assert_close(out, ref, 1e-5, 1e-6, case + " vs " + kn0)
+    eps_w = F.rng_fill_normal(9, 4, 2, 1, 0, S, mu.shape, dev).cpu()
+    eps_b = F.rng_fill_normal(9, 4, 2, 1, 1, S, (mu.shape[0],), dev).cpu()
+    B = x.shape[0] // S
+    for s in range(S):
+        xs = x[s * B:s * B + 16].cpu()
+        want = torch.relu(CO.reparam_fwd(xs, mu.cpu(), rho.cpu(), eps_w[s], mb.cpu(), rb.cpu(), eps_b[s], conv))
+        assert_close(out[s * B:s * B + 16].cpu(), want, RTOL, ATOL, f"{case}[s={s}] vs C oracle")
