@@ -278,7 +278,11 @@ __global__ __launch_bounds__(kDirectThreads) void fused_split_direct_kernel(cons
   head_load(xr[1]);
   head_load(xr[2]);
 
-  // four K16 steps from the weight image at wq (its step 0 = the block's first step), x from the ring
+  // Four K16 steps from the weight image at wq (its step 0 = the block's first step), x from the ring.
+  // (Round 3, measured: software-pipelining the split of the next unit behind the current unit's MFMAs with sched_group_barrier -- one
+  // MFMA, four VALU, ... in the emitted code -- changes nothing: 2.94 ms either way on ResNet50's layer3 conv3. PMC of that launch:
+  // matrix pipe busy 52 %, VALU busy 45 % of a shader clock that averages ~1.35 GHz of the 2.4 GHz it could run at: the launch sits at
+  // the power limit, and what it needs is fewer instructions and bytes per MFMA, not a denser schedule.)
   f32x16 acc[TN][TM];
   auto four_steps = [&](const char* wq, auto&& mid) {
 #pragma unroll

@@ -144,7 +144,8 @@ def launch_ranks(n, argv):
             p.kill()
     rd.join(timeout=5)
     text = (out0[0] if out0 else b"").decode(errors="replace")
-    sys.stdout.write(text)
+    for ln in text.splitlines():          # rank 0's JSON line goes to stdout; anything else it printed there (a backend's banner) to stderr
+        print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr)
     sys.stdout.flush()
     if rc == 0 and not any(ln.startswith("{") for ln in text.splitlines()):
         print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
@@ -432,6 +433,8 @@ def _rocprof_name(kn):
         return r"fused_split_kernel<\s*%s,\s*%s,\s*%s,\s*%s,\s*%s,\s*(false|0)" % m.groups()
     if kn.startswith("fused_split_quad_kernel"):
         return r"fused_split_quad_kernel<"
+    if kn.startswith("fused_split_direct_kernel"):
+        return r"fused_split_direct_kernel<\s*(true|1)\s*>" if "resident" in kn else r"fused_split_direct_kernel<\s*(false|0)\s*>"
     return None
 
 
@@ -480,7 +483,8 @@ def traffic_object(pmc, dom_name, dom_bytes_alg, step_bytes_alg, launches_per_st
         return f, wr, nf, nw
     pat = _rocprof_name(dom_name)
     out = dict(measured=True, how="two child `rocprofv3 --pmc` passes of this command (FETCH_SIZE, WRITE_SIZE; 3 steps, graph replay), started before this "
-               "process touched the GPU; corrected per MI355X_MICROARCH.md (HBM): FETCH_SIZE x 2 (16-byte-per-lane streaming reads are tallied at half), WRITE_SIZE as is; counter unit KB")
+               "process touched the GPU; corrected per MI355X_MICROARCH.md (HBM): FETCH_SIZE x 2 (16-byte-per-lane streaming reads are tallied at half), WRITE_SIZE as is; counter unit KB. "
+               "The guide calibrates the x2 for 16-byte-per-lane reads only: the direct 1x1 kernels fetch x with 4-byte-per-lane loads, for which the raw figure may be the right one -- both are given")
     f, wr, nf, nw = agg(lambda k: "fused_" in k)
     if nf and nw:
         out["fused_launch_avg_bytes"] = round((2.0 * f / nf + wr / nw) * 1024.0)

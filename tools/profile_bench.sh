@@ -3,11 +3,13 @@
 # Outputs under gpurun_out/prof_<tag>/ ; summaries are copied to profiles/ by hand (tracked).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=${1:-r01}
-args="--steps 10 --warmup 3 --no-cpu-baseline"
+wl=${2:-cfg3}
+steps=${3:-10}
+args="--workload $wl --steps $steps --warmup 2 --no-cpu-baseline --no-traffic --no-extras --no-parity"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_stats -- python bench.py $args > gpurun_out/prof_${tag}_stats.log 2>&1
 # PMC passes are separate runs with nothing but the counters (FETCH_SIZE and WRITE_SIZE do not fit one pass)
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_${tag}_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/prof_${tag}_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_${tag}_write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/prof_${tag}_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_${tag}_fetch -- python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-traffic --no-extras --no-parity > gpurun_out/prof_${tag}_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_${tag}_write -- python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-traffic --no-extras --no-parity > gpurun_out/prof_${tag}_write.log 2>&1
 python - "$tag" <<'PY'
 import csv, glob, json, sys, collections
 tag = sys.argv[1]
@@ -20,6 +22,7 @@ if f:
     ft = sum(float(r["TotalDurationNs"]) for r in fused); fc = sum(int(r["Calls"]) for r in fused)
     out["kernel_stats"] = dict(fused_calls=fc, fused_total_ms=ft / 1e6, fused_avg_us=ft / fc / 1e3, fused_share_of_gpu_time=ft / tot)
     print("top kernels:")
+    import shutil; shutil.copy(f[0], f"gpurun_out/prof_{tag}_kernel_stats.csv")
     for r in rows[:16]:
         print(f"  {r['Percentage']:>6}%  {int(r['Calls']):5d} calls  avg {float(r['AverageNs'])/1e3:9.1f} us  {r['Name'][:150]}")
 for name in ("fetch", "write"):
