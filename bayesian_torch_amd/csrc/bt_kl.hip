@@ -79,14 +79,26 @@ __global__ __launch_bounds__(kKlThreads) void kl_normal_kernel(KlSegs sg, float*
   if (threadIdx.x == 0) is_last = publish_and_ticket(slots, counter, blockIdx.x, bsum, (unsigned)total_blocks) ? 1 : 0;
   __syncthreads();
   if (!is_last) return;
-  // last arriver: fixed-order finish. mean per segment in fp64 -> fp32, segments added in fp32
-  // (the reference adds fp32 0-dim tensors: kl_weight + kl_bias, then += across layers).
+  // last arriver: fixed-ORDER finish, in parallel. A segment's block partials are summed by the 256 threads in a fixed tree (thread t
+  // adds the slots t, t + 256, ... in increasing order; then the wave butterflies and the four wave sums in index order): the same
+  // tree every time, so the result is deterministic -- and a whole model's ~2,700 slots no longer pass through ONE thread's serial
+  // chain of agent-scope loads (round 3: that chain was 429 us of a 3.95 ms ResNet18 training step, and of every get_kl_loss()).
+  // mean per segment in fp64 -> fp32, segments added in fp32 (the reference adds fp32 0-dim tensors: kl_weight + kl_bias, then += across layers).
+  __shared__ double seg_sum[BT_KL_MAX_SEGMENTS];
+  for (int s = 0; s < sg.nseg; ++s) {
+    double t = 0.0;
+    for (int b = sg.first_block[s] + (int)threadIdx.x; b < sg.first_block[s + 1]; b += kKlThreads) t += __hip_atomic_load(&slots[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = wave_sum(t);
+    __syncthreads();   // (red is free again)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) seg_sum[s] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     float total = 0.0f, layer = 0.0f;
     for (int s = 0; s < sg.nseg; ++s) {
-      double ssum = 0.0;
-      for (int b = sg.first_block[s]; b < sg.first_block[s + 1]; ++b) ssum += __hip_atomic_load(&slots[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float mean = (float)(ssum / (double)sg.n[s]);
+      const float mean = (float)(seg_sum[s] / (double)sg.n[s]);
       if ((sg.new_layer >> s) & 1ull) {
         if (s) total += layer;  // 0.0f + x is exact, so the first layer enters unrounded
         layer = mean;

@@ -90,28 +90,43 @@ __global__ __launch_bounds__(kFpThreads) void pack_fingerprint_kernel(PackSegs s
   if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// packed[(co*T + t)*C4 + c] <- natural[co][c][t] for the segments marked dirty (the layout of bt_pack_params)
+// packed[(co*T + t)*C4 + c] <- natural[co][c][t] for the segments marked dirty (the layout of bt_pack_params). A work item is (row co,
+// chunk of 64 channels): its 64 x T natural floats are one contiguous run -- read coalesced, transposed through LDS, written as T runs
+// of 64 packed floats (a training step rebuilds every pack: read straight in packed order the natural tensors were fetched at a
+// stride of T floats, 99 us per ResNet18 step).
+constexpr int kPackCh = 64;
 __global__ __launch_bounds__(256) void pack_dirty_kernel(PackSegs sg) {
+  extern __shared__ float2 tile[];   // [T][64 + 1] (mu, sigma)
   int seg = 0;
   while (seg + 1 < sg.nseg && (int)blockIdx.x >= sg.first_block[seg + 1]) ++seg;
   if (__hip_atomic_load(&sg.state[seg][2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;
   const int nb = sg.first_block[seg + 1] - sg.first_block[seg], lb = blockIdx.x - sg.first_block[seg];
-  const long long C = sg.C[seg], T = sg.T[seg], C4 = (C + 3) & ~3ll, n = sg.np[seg];
+  const long long C = sg.C[seg], T = sg.T[seg], C4 = (C + 3) & ~3ll;
+  const long long Co = sg.np[seg] / (T * C4);
+  const long long cchunks = (C4 + kPackCh - 1) / kPackCh, items = Co * cchunks;
   const float* __restrict__ mu = sg.src_mu[seg];
   const float* __restrict__ rho = sg.src_rho[seg];
   float* __restrict__ mu_p = sg.mu_p[seg];
   float* __restrict__ sg_p = sg.sg_p[seg];
-  for (long long i = (long long)lb * 256 + threadIdx.x; i < n; i += (long long)nb * 256) {
-    const long long c = i % C4, rt = i / C4;
-    const long long t = rt % T, co = rt / T;
-    float m = 0.f, s = 0.f;
-    if (c < C) {
-      const long long src = (co * C + c) * T + t;
-      m = mu[src];
-      s = softplus(rho[src]);
+  const int Ti = (int)T;
+  for (long long it = lb; it < items; it += nb) {
+    const long long co = it / cchunks, c0 = (it - co * cchunks) * kPackCh;
+    const int nc = (int)((C - c0) < kPackCh ? (C - c0 > 0 ? C - c0 : 0) : kPackCh);      // real channels of this chunk
+    const int nc4 = (int)((C4 - c0) < kPackCh ? (C4 - c0) : kPackCh);                     // packed channels (padding holds zeros)
+    const long long src0 = (co * C + c0) * T;
+    __syncthreads();   // (the previous item's tile has been written out)
+    for (int i = threadIdx.x; i < nc * Ti; i += 256) {
+      const int c = i / Ti, t = i - c * Ti;
+      tile[t * (kPackCh + 1) + c] = make_float2(mu[src0 + i], softplus(rho[src0 + i]));
     }
-    mu_p[i] = m;
-    sg_p[i] = s;
+    __syncthreads();
+    for (int j = threadIdx.x; j < Ti * nc4; j += 256) {
+      const int t = j / nc4, c = j - t * nc4;
+      const float2 v = c < nc ? tile[t * (kPackCh + 1) + c] : make_float2(0.f, 0.f);
+      const long long dst = (co * T + t) * C4 + c0 + c;
+      mu_p[dst] = v.x;
+      sg_p[dst] = v.y;
+    }
   }
 }
 
@@ -139,18 +154,34 @@ extern "C" int bt_pack_sync(int32_t n_segments, const bt_pack_seg* segs, void* w
     if (s.force) fp.force |= 1ull << i;
   }
   pk = fp;
+  long long max_taps = 1;
   for (int i = 0; i < n_segments; ++i) {
+    const bt_pack_seg& s_ = segs[i];
     long long nb = (fp.n[i] + kFpElemsPerBlock - 1) / kFpElemsPerBlock;
     if (nb > 128) nb = 128;
     fp.first_block[i] = fblocks, fblocks += (int)nb;
-    long long pb = (fp.np[i] + 1023) / 1024;   // 4 packed elements per thread
+    const long long C4 = (s_.Ci + 3) & ~3ll;
+    long long pb = s_.Co * ((C4 + kPackCh - 1) / kPackCh);   // (row, 64-channel chunk) work items
     if (pb > 256) pb = 256;
     pk.first_block[i] = pblocks, pblocks += (int)pb;
+    if (s_.taps > max_taps) max_taps = s_.taps;
   }
   fp.first_block[n_segments] = fblocks, pk.first_block[n_segments] = pblocks;
   fp.nseg = pk.nseg = n_segments;
   hipLaunchKernelGGL(pack_fingerprint_kernel, dim3(fblocks), dim3(kFpThreads), 0, (hipStream_t)stream, fp, ws_counter(workspace), fblocks);
   if (int rc = check_launch("bt_pack_sync (fingerprint)")) return rc;
-  hipLaunchKernelGGL(pack_dirty_kernel, dim3(pblocks), dim3(256), 0, (hipStream_t)stream, pk);
+  const size_t lds = (size_t)max_taps * (kPackCh + 1) * sizeof(float2);
+  if (max_taps > 128) return set_error(BT_ERR_UNSUPPORTED, "bt_pack_sync: kernels larger than 128 taps are not supported");
+  if (lds > 48 * 1024) {   // (above the default dynamic-LDS limit: 11 x 11 kernels and larger)
+    static bool flags[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return set_error(BT_ERR_HIP_BASE, "bt_pack_sync: hipGetDevice failed");
+    if (!flags[dev]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(pack_dirty_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (kPackCh + 1) * (int)sizeof(float2)) != hipSuccess)
+        return set_error(BT_ERR_HIP_BASE, "bt_pack_sync: cannot raise the dynamic LDS limit");
+      flags[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL(pack_dirty_kernel, dim3(pblocks), dim3(256), lds, (hipStream_t)stream, pk);
   return check_launch("bt_pack_sync (pack)");
 }
