@@ -149,6 +149,8 @@ class FusedBayesLayer(BaseVariationalLayer_):
         (``mc.sync_model_packs``); a layer called on its own checks itself."""
         ctx = mc.current()
         if ctx is not None and id(self) in ctx.synced and self._pack is not None and not self._pack_force:
+            if id(self) in ctx.late:
+                mc.join_packs(ctx)      # this layer's pack was verified on the side stream: the launch stream waits for it (once)
             return self._pack[1], self._pack[2]
         F.pack_sync([self._pack_segment()], owner=("layer", self._ws_id))
         return self._pack[1], self._pack[2]
