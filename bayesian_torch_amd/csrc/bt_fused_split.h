@@ -56,6 +56,20 @@ __device__ __forceinline__ void split_pieces(float v, uint32_t& h, uint32_t& m, 
 __device__ __forceinline__ uint32_t pack_hi16(uint32_t hi, uint32_t lo) {  // (hi.upper16 << 16) | lo.upper16
   return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
 }
+// The same split for two values at once, straight to the packed bf16 pairs (b in the upper half): the two exact subtractions run as
+// packed fp32 operations (v_pk_add_f32: one instruction for both values) -- 7 instead of 9.5 instructions per pair. Same IEEE
+// operations, so the pieces are bit for bit split_pieces'.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+  const f32x2_t v = {a, b};
+  const u32x2_t hb = __builtin_bit_cast(u32x2_t, v) & 0xFFFF0000u;
+  const f32x2_t r = v - __builtin_bit_cast(f32x2_t, hb);        // exact
+  const u32x2_t mb = __builtin_bit_cast(u32x2_t, r) & 0xFFFF0000u;
+  const f32x2_t q = r - __builtin_bit_cast(f32x2_t, mb);        // exact; <= 8 significant bits
+  const u32x2_t lb = __builtin_bit_cast(u32x2_t, q);
+  h = pack_hi16(hb.y, hb.x), m = pack_hi16(mb.y, mb.x), l = pack_hi16(lb.y, lb.x);
+}
 
 // n / d with the host's reciprocal (bt_fused_split_host.h: inv == 0 -> divide; d == 1 needs none)
 __device__ __forceinline__ int udiv_inv(int n, int d, uint32_t inv) {
