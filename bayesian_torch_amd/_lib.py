@@ -59,6 +59,7 @@ _PROTOS = {
     "bt_last_error_string": (C.c_char_p, []),
     "bt_last_kernel_name": (C.c_char_p, []),
     "bt_last_launch_info": (C.c_int, [C.POINTER(C.c_int64), C.c_int32]),
+    "bt_fused_scratch_bytes": (C.c_size_t, [C.POINTER(bt_conv2d_geom), C.c_int32]),
     "bt_set_contraction": (C.c_int, [C.c_int]),
     "bt_conv2d_bwd_workspace": (C.c_size_t, [C.POINTER(bt_conv2d_geom), C.c_int32]),
     "bt_conv2d_bwd": (C.c_int, [C.POINTER(bt_conv2d_geom), C.c_int32, C.c_int32, _vp, C.c_int64, _vp, C.POINTER(bt_params), C.POINTER(bt_draws),
@@ -148,14 +149,19 @@ def on(device):
 
 
 _ws = {}
+_ws_retired = []
 
 
-def workspace(key, device):
-    """One zero-initialised BT_WORKSPACE_BYTES buffer per (owner, device); kernels leave it zeroed."""
+def workspace(key, device, scratch=0):
+    """One zero-initialised BT_WORKSPACE_BYTES buffer per (owner, device); kernels leave it zeroed. ``scratch`` more bytes behind it
+    (bt_fused_scratch_bytes: the split-K forwards' slabs; contents never matter) -- the buffer grows when a call asks for more."""
     k = (key, device.index if device.index is not None else torch.cuda.current_device())
     w = _ws.get(k)
-    if w is None:
-        w = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    need = WORKSPACE_BYTES + ((int(scratch) + 255) // 256) * 256
+    if w is None or w.numel() < need:
+        if w is not None:
+            _ws_retired.append(w)    # (a captured graph may still hold the smaller buffer's address)
+        w = torch.zeros(need, dtype=torch.uint8, device=device)
         _ws[k] = w
     return w
 

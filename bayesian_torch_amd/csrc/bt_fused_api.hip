@@ -55,6 +55,12 @@ static int run(bool flip, bool linear, const bt_conv2d_geom& g, int S, const flo
   a.out = out, a.kl_out = kl_out;
   a.slots = kl_out ? ws_slots(ws) : nullptr;
   a.counter = kl_out ? ws_counter(ws) : nullptr;
+  // a workspace larger than BT_WORKSPACE_BYTES carries scratch for the split-K (skinny) flavour behind its zeroed head
+  if (ws && ws_bytes > BT_WORKSPACE_BYTES) {
+    a.sk_scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + BT_WORKSPACE_BYTES);
+    a.sk_scratch_bytes = (long long)(ws_bytes - BT_WORKSPACE_BYTES);
+    a.sk_tickets = reinterpret_cast<unsigned*>(ws_slots(ws) + 4000);
+  }
   a.B = g.B, a.Ci = g.Ci, a.H = g.H, a.W = g.W, a.Co = g.Co, a.KH = g.kh, a.KW = g.kw;
   a.SH = g.sh, a.SW = g.sw, a.PH = g.ph, a.PW = g.pw, a.DH = g.dh, a.DW = g.dw, a.G = g.groups;
   a.Ho = Ho, a.Wo = Wo, a.HoWo = Ho * Wo;
@@ -146,6 +152,13 @@ extern "C" int bt_flipout_conv2d_fwd(const bt_conv2d_geom* g, int32_t S, const f
                                      const bt_draws* d, const bt_epilogue* ep, float* out, float* kl_out, void* ws, size_t ws_bytes, bt_stream_t stream) {
   if (!g) return bt::set_error(BT_ERR_BAD_ARG, "bt_flipout_conv2d_fwd: null geometry");
   return bt::run(true, false, *g, S, x, x_sample_stride, p, d, ep, out, kl_out, ws, ws_bytes, stream, "bt_flipout_conv2d_fwd");
+}
+
+namespace bt { long long skinny_scratch_bytes(const bt_conv2d_geom& g, int S); }
+extern "C" size_t bt_fused_scratch_bytes(const bt_conv2d_geom* g, int32_t S) {
+  if (!g || S <= 0) return 0;
+  const long long n = bt::skinny_scratch_bytes(*g, S);
+  return n > 0 ? (size_t)n : 0;
 }
 
 extern "C" int bt_last_launch_info(int64_t* out, int32_t n) {

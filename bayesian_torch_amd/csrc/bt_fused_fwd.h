@@ -72,6 +72,12 @@ struct FwdArgs {
   uint32_t inv_m_tiles, inv_S, inv_n_tiles, inv_n_bt, inv_n_ct, inv_rw, inv_wt, inv_kw;
   int x_flat;  // split flavour, XM 3: the patch is the whole input plane -- fetch it as one row of H*W pixels
   int row_taps;  // split flavour: tiles = t_NI images x ONE output row; the active taps are those of the tile's row (2-row maps)
+  // skinny flavour (bt_fused_split_skinny.h): scratch slabs behind the workspace, tickets inside it, slice geometry
+  float* sk_scratch;
+  unsigned* sk_tickets;
+  long long sk_scratch_bytes;
+  int sk_nsl, sk_ks, sk_cpt;           // slices per tile, slice width (channels), slices per tap
+  int sk_kh0, sk_nh, sk_kw0, sk_nw;    // the rectangle of taps whose input pixel exists for the one output pixel
   int d_tap;     // direct flavour: the ONE tap of the kernel window that meets data (0 for 1x1 kernels; the centre of a padded window over a 1x1 image)
 };
 

@@ -5,6 +5,7 @@
 
 #include "bt_fused_split_quad.h"
 #include "bt_fused_split_direct.h"
+#include "bt_fused_split_skinny.h"
 #include "bt_fused_split_host.h"
 
 namespace bt {
@@ -181,6 +182,73 @@ static int launch_direct(FwdArgs& a, hipStream_t stream) {
   return launch(fused_split_direct_kernel<false>, "fused_split_direct_kernel<64,8x64,bf16x3,6 terms,streamed W>", fs, direct_lds_bytes(kDirectMaxK + 1));
 }
 
+// Layers whose output map is one pixel and whose batch is small (Linear, CIFAR-sized layer4, the classifier head): the split-K kernel of
+// bt_fused_split_skinny.h. Geometry of the slices from the layer alone, so the K order never depends on S or on the launch split.
+struct SkinnyPlan { int ks, cpt, kh0, nh, kw0, nw, nsl, n_tiles, m_tiles; long long tiles, scratch; };
+static bool skinny_plan(int B, int Ci, int H, int W, int Co, int KH, int KW, int PH, int PW, int DH, int DW, int G, int Ho, int Wo, int S, SkinnyPlan* p) {
+  if (Ho != 1 || Wo != 1 || B > 1024 || KH * KW > 64) return false;
+  const int Cig = Ci / G, Cog = Co / G;
+  if (Cig & 63) return false;
+  const int kh0 = (PH + DH - 1) / DH, kw0 = (PW + DW - 1) / DW;              // first tap with kh * DH - PH >= 0
+  int kh1 = (PH + H - 1) / DH, kw1 = (PW + W - 1) / DW;                      // last tap with kh * DH - PH <= H - 1
+  if (kh1 > KH - 1) kh1 = KH - 1;
+  if (kw1 > KW - 1) kw1 = KW - 1;
+  if (kh1 < kh0 || kw1 < kw0) return false;
+  p->kh0 = kh0, p->nh = kh1 - kh0 + 1, p->kw0 = kw0, p->nw = kw1 - kw0 + 1;
+  p->ks = (Cig & 127) ? 64 : 128;
+  p->cpt = Cig / p->ks;
+  p->nsl = p->nh * p->nw * p->cpt;
+  p->n_tiles = (Cog + 63) / 64, p->m_tiles = (B + kSkinnyCols - 1) / kSkinnyCols;
+  // Measured on ResNet18 / CIFAR (S = 32, b128, rocprofv3 inside the bench graph, tools/trace_layers.py): the classifier head (4
+  // workgroups per sample) 37.6 -> 23.8 us; the 1x1 stride-2 downsample into layer4 (16 per sample) 40.7 -> 43.9 against the direct
+  // kernel; layer4's 3x3 layers with one live tap (32 per sample) 53 ... 60 -> 60; layer4.0.conv1 with four live taps (64 per sample,
+  // 2048 workgroups) 71 -> 140: past a few slices per sample the slabs' HBM round trip (2 x 32 KB per workgroup) and the second round
+  // of workgroups cost more than the shorter chains save. So: narrow heads only. The bound is per SAMPLE -- geometry, not S.
+  if ((long long)G * p->m_tiles * p->n_tiles * p->nsl > 8) return false;
+  p->tiles = (long long)G * S * p->m_tiles * p->n_tiles;
+  if (p->tiles > kSkinnyMaxTiles || p->tiles * p->nsl > 0x7FFFFFFFll) return false;
+  p->scratch = p->tiles * p->nsl * (64ll * kSkinnyCols * 4);
+  return true;
+}
+long long skinny_scratch_bytes(const bt_conv2d_geom& g, int S) {
+  if (g.B <= 0 || g.Ci <= 0 || g.Co <= 0 || g.groups <= 0 || g.Ci % g.groups || g.Co % g.groups || g.sh <= 0 || g.sw <= 0 || g.dh <= 0 || g.dw <= 0) return 0;
+  const int Ho = (g.H + 2 * g.ph - g.dh * (g.kh - 1) - 1) / g.sh + 1, Wo = (g.W + 2 * g.pw - g.dw * (g.kw - 1) - 1) / g.sw + 1;
+  SkinnyPlan p;
+  return skinny_plan(g.B, g.Ci, g.H, g.W, g.Co, g.kh, g.kw, g.ph, g.pw, g.dh, g.dw, g.groups, Ho, Wo, S, &p) ? p.scratch : 0;
+}
+static std::atomic<int> g_skinny_off{-1};
+static int launch_skinny(FwdArgs& a, hipStream_t stream) {
+  int off = g_skinny_off.load(std::memory_order_relaxed);
+  if (off < 0) {   // env BT_NO_SKINNY=1: measurement knob (tools/trace_layers.py), like the test hook below
+    const char* e = getenv("BT_NO_SKINNY");
+    off = (e && *e && *e != '0') ? 1 : 0;
+    g_skinny_off.store(off, std::memory_order_relaxed);
+  }
+  if (off || a.ep_pool || !a.sk_scratch || !a.sk_tickets) return 1;
+  SkinnyPlan p;
+  if (!skinny_plan(a.B, a.Ci, a.H, a.W, a.Co, a.KH, a.KW, a.PH, a.PW, a.DH, a.DW, a.G, a.Ho, a.Wo, a.S, &p)) return 1;
+  if (p.scratch > a.sk_scratch_bytes) return 1;   // the caller brought no (or too little) scratch: the other flavours serve the launch
+  if ((((uintptr_t)a.sk_scratch) & 15u)) return 1;
+  a.sk_ks = p.ks, a.sk_cpt = p.cpt, a.sk_nsl = p.nsl, a.sk_kh0 = p.kh0, a.sk_nh = p.nh, a.sk_kw0 = p.kw0, a.sk_nw = p.nw;
+  a.n_tiles = p.n_tiles, a.m_tiles = p.m_tiles;
+  a.t_NI = kSkinnyCols, a.t_R = 1, a.t_Wt = 1, a.n_bt = p.m_tiles, a.n_rt = a.n_ct = 1;
+  a.total_blocks = (int)(p.tiles * p.nsl);
+  a.kl_slices = a.total_blocks < 256 ? a.total_blocks : 256;   // (spread over every workgroup the sweep lengthened all of them: 50 -> 62 us on ResNet18 layer4)
+  a.x_vec = (a.HW == 1 && ((((uintptr_t)a.x) & 15u) == 0) && (a.x_sample_stride & 3) == 0 && (a.Ci & 3) == 0) ? 1 : 0;
+  const int lds = skinny_lds_bytes(p.ks);
+  static bool flags[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return set_error(BT_ERR_HIP_BASE, "fused forward (split, skinny): hipGetDevice failed");
+  if (!flags[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fused_split_skinny_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, skinny_lds_bytes(128)) != hipSuccess)
+      return set_error(BT_ERR_HIP_BASE, "fused forward (split, skinny): cannot raise the dynamic LDS limit");
+    flags[dev] = true;
+  }
+  note_kernel(p.ks == 128 ? "fused_split_skinny_kernel<64,4x32,bf16x3,6 terms,split-K 128>" : "fused_split_skinny_kernel<64,4x32,bf16x3,6 terms,split-K 64>");
+  hipLaunchKernelGGL(fused_split_skinny_kernel, dim3((unsigned)a.total_blocks), dim3(kSkinnyThreads), lds, stream, a);
+  return check_launch("fused forward (split, skinny)");
+}
+
 // Returns BT_OK when the launch was taken, 1 when this flavour does not apply (the caller runs the fp32 kernels), < 0 on error.
 static int launch_split_one(FwdArgs& a, hipStream_t stream) {
   const int mode = contraction_mode();
@@ -189,12 +257,16 @@ static int launch_split_one(FwdArgs& a, hipStream_t stream) {
   if (!a.mu_pk || (((uintptr_t)a.mu_pk | (uintptr_t)a.sig_pk) & 15u) || a.w_elems >= (1ll << 29) || a.x_elems >= (1ll << 29)) return 1;
   if (a.Cig <= 4) return launch_quad(a, mode, stream);   // the stems
   // whole channel octets, at most 9 taps, no fused pooling
-  if ((a.Cig & 7) || a.T > 9 || a.ep_pool) return 1;
-  if (mode != 2) {
+  if ((a.Cig & 7) || a.ep_pool) return 1;
+  if (mode != 2) {   // (the flavours with a single live tap per slice / layer take any window size)
+    FwdArgs k = a;
+    const int rck = launch_skinny(k, stream);
+    if (rck <= 0) { a = k; return rck; }
     FwdArgs d = a;
     const int rcd = launch_direct(d, stream);
     if (rcd <= 0) { a = d; return rcd; }
   }
+  if (a.T > 9) return 1;
   const int Mdom = a.pixel_major ? a.B : a.M;
   if (Mdom < 112) return 1;
   a.n_tiles = (a.Cog + 63) / 64;
@@ -261,6 +333,7 @@ int launch_split(FwdArgs& a, hipStream_t stream) {
     t.out_vec4 = 0;   // 2..4-pixel rows: the scalar output stage
     rc = launch_split_one(t, stream);
   }
+  if (rc <= 0) a = t;   // the plan that ran (bt_last_launch_info reads it)
   return rc;
 }
 
@@ -268,6 +341,7 @@ int launch_split(FwdArgs& a, hipStream_t stream) {
 
 // Test hook (not part of include/bt_hip.h): 1 keeps 1x1 convolutions off the direct kernel, so a test can compare the two flavours.
 extern "C" void bt_debug_disable_direct(int off) { bt::g_direct_off.store(off ? 1 : 0, std::memory_order_relaxed); }
+extern "C" void bt_debug_disable_skinny(int off) { bt::g_skinny_off.store(off ? 1 : 0, std::memory_order_relaxed); }
 
 // Contraction arithmetic of the fused forwards (process-wide knob; also env BT_CONTRACTION = f32 | bf16x3 | bf16x2):
 // 0 automatic -- exact bf16x3 split (6 product terms, fp32 accumulate) on the bf16 matrix pipe wherever the launch is eligible,

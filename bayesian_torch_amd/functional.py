@@ -73,12 +73,18 @@ def _fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=No
     out = torch.empty((S * B,) + tail, dtype=torch.float32, device=dev)
     kl = ws = None
     pr = [None] * 4
+    L = _lib.lib()
+    # layers whose output map is one pixel may run split over K-slices that meet in scratch behind the workspace (include/bt_hip.h)
+    gq = geom if conv is not None else _lib.bt_conv2d_geom(B, In, 1, 1, Co, 1, 1, 1, 1, 0, 0, 1, 1, 1)
+    scratch = int(L.bt_fused_scratch_bytes(C.byref(gq), S)) if (eps_w is None and not flip and packed is not None) else 0
+    if scratch:
+        ws = _lib.workspace(workspace_owner, dev, scratch)
     if want_kl:
         if priors is None:
             raise ValueError("want_kl needs priors")
         pr = [_lib.dev_f32(t, "prior") for t in priors]
         kl = torch.empty((), dtype=torch.float32, device=dev)
-        ws = _lib.workspace(workspace_owner, dev)
+        ws = _lib.workspace(workspace_owner, dev, scratch)
     P = _lib.bt_params(tens["mu_w"].data_ptr(), tens["rho_w"].data_ptr(), _lib.ptr(tens["mu_b"]), _lib.ptr(tens["rho_b"]),
                        _lib.ptr(pr[0]), _lib.ptr(pr[1]), _lib.ptr(pr[2]), _lib.ptr(pr[3]), _lib.ptr(tens["mu_packed"]), _lib.ptr(tens["sigma_packed"]),
                        _lib.PRIOR_LAPLACE if prior_type == "laplace" else _lib.PRIOR_NORMAL, 0)
@@ -96,8 +102,7 @@ def _fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=No
             raise RuntimeError("post_scale / post_shift must both have Co elements")
         E = C.byref(_lib.bt_epilogue(_lib.ptr(tens["post_scale"]), _lib.ptr(tens["post_shift"]), _lib.ptr(res), rstride, 1 if relu else 0, 1 if pool else 0))
     tail_args = (x.data_ptr(), 0 if shared_x else x_elems, C.byref(P), C.byref(D), E, out.data_ptr(), _lib.ptr(kl), _lib.ptr(ws),
-                 _lib.WORKSPACE_BYTES if want_kl else 0, _lib.stream_ptr(dev))
-    L = _lib.lib()
+                 ws.numel() if ws is not None else 0, _lib.stream_ptr(dev))
     with _lib.on(dev):
         if conv is None:
             fn = L.bt_flipout_linear_fwd if flip else L.bt_reparam_linear_fwd

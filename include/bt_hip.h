@@ -125,6 +125,12 @@ const char *bt_last_error_string(void);
 /* Diagnostic: the kernel instance (template name and tile) the calling thread's last fused-forward launch selected --
  * lets a benchmark attribute per-launch times to kernel instances the way rocprofv3's kernel trace does. */
 const char *bt_last_kernel_name(void);
+/* Scratch the split-K flavour of the forwards wants for this geometry (layers whose output map is one pixel: Linear, 1x1-map
+ * convolutions; 0 for every other layer). Optional: hand the forward a workspace of BT_WORKSPACE_BYTES + this many bytes -- the
+ * head zero-filled as always, the rest uninitialised -- and it may split the contraction over K-slices that meet in the scratch (a
+ * fixed-order, deterministic combine); with a plain BT_WORKSPACE_BYTES workspace the other kernels serve the launch. */
+size_t bt_fused_scratch_bytes(const bt_conv2d_geom *g, int32_t S);
+
 /* ... and that launch's tile geometry, for a benchmark's roofline model: out[0..n) <- {workgroups, m_tiles, n_tiles, S, images per
  * tile, output rows per tile, output columns per tile, pixel_major, row_tiles, kl_slices, groups, n_bt, n_rt, n_ct, fused KL, 0}. */
 int bt_last_launch_info(int64_t *out, int32_t n);

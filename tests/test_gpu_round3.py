@@ -304,11 +304,13 @@ def test_direct_kernel_on_one_pixel_images_and_linear(case):
 
     def run(direct):
         L.bt_debug_disable_direct(0 if direct else 1)
+        L.bt_debug_disable_skinny(1)   # (narrow heads would go to the split-K flavour first: its own test)
         try:
             out, _ = F.fused_forward(x, mu, rho, mb, rb, conv=conv, S=S, shared_x=False, seed=9, call=4, layer_id=2, sample0=1, packed=pk, relu=True)
             return out, L.bt_last_kernel_name().decode()
         finally:
             L.bt_debug_disable_direct(0)
+            L.bt_debug_disable_skinny(0)
     out, kn = run(True)
     assert "fused_split_direct_kernel" in kn and ("streamed" in kn) == ("streamed" in case), kn
     ref, kn0 = run(False)
@@ -344,3 +346,100 @@ def test_bench_bare_command_launches_two_ranks_on_one_gpu():
     assert len(rows) == 1 and len(p.stdout.decode().strip().splitlines()) == 1, p.stdout.decode()[:500]
     d = json.loads(rows[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_samples_per_step"] == 16 and d["value"] > 0
+
+
+# ------------------------------------------------------------------------------------------------ the split-K ("skinny") kernel
+# kind, Ci, Co, k, stride, pad, dil, groups, H, B, S, bias, extras
+SKINNY = {   # (kind, Ci, Co, k, stride, pad, dil, groups, H, B, S, bias, extras) -- at most 8 workgroups per sample (launch_skinny's gate)
+    "classifier head: Linear 512 -> 10, b128, bias (10 of 64 rows; 4 slices)": ("linear", 512, 10, 1, 1, 0, 1, 1, 1, 128, 3, True, False),
+    "cfg2 head: Linear 512 -> 10, b256 (2 column tiles x 4 slices), bias + ReLU": ("linear", 512, 10, 1, 1, 0, 1, 1, 1, 256, 2, True, True),
+    "Linear 1024 -> 64, b100 (partial column tile, 8 slices), residual + BN + ReLU": ("linear", 1024, 64, 1, 1, 0, 1, 1, 1, 100, 2, True, True),
+    "2x2 valid over 2x2 maps (1x1 out, all 4 taps live, slices of 64), 64 -> 48, b100": ("conv", 64, 48, 2, 1, 0, 1, 1, 2, 100, 2, True, False),
+    "1x1 stride 2, 2x2 -> 1x1, 256 -> 64 (2 slices)": ("conv", 256, 64, 1, 2, 0, 1, 1, 2, 128, 2, False, True),
+    "groups 2: 3x3 pad 1 over 1x1 maps, 128 -> 40 (one slice of 64 per group), b33": ("conv", 128, 40, 3, 1, 1, 1, 2, 1, 33, 2, True, True),
+    "3x3 dilation 2 pad 2 over 1x1 maps (centre tap), 128 -> 100 (2 channel tiles)": ("conv", 128, 100, 3, 1, 2, 2, 1, 1, 64, 2, True, False),
+}
+
+
+@pytest.mark.parametrize("name", list(SKINNY))
+def test_skinny_split_k_kernel_vs_c_oracle_and_general_kernel(name):
+    """bt_fused_split_skinny.h: one-pixel output maps split over K-slices that meet in scratch slabs, combined in slice order by the
+    last arriver. Against the C oracle (fp64 accumulation) on the materialised draws at the unchanged tolerance, against the
+    general kernels on the same draws (its K order is its own: close, not equal), run twice (deterministic: bit-identical), and
+    with the samples launched one at a time (same global sample ids: bit-identical)."""
+    from oracle import c_oracle as CO
+    from bayesian_torch_amd import _lib
+    from bayesian_torch_amd import functional as F
+    kind, Ci, Co, k, st, pd, dl, grp, H, B, S, bias, extras = SKINNY[name]
+    g = torch.Generator().manual_seed(abs(hash(name)) % (1 << 31))
+    dev = torch.device("cuda")
+    if kind == "linear":
+        mu, rho = (torch.randn(Co, Ci, generator=g) * 0.1).to(dev), (torch.randn(Co, Ci, generator=g) * 0.1 - 3).to(dev)
+        x = torch.randn(S * B, Ci, generator=g).to(dev)
+        conv, oshape = None, (Co,)
+    else:
+        mu, rho = (torch.randn(Co, Ci // grp, k, k, generator=g) * 0.1).to(dev), (torch.randn(Co, Ci // grp, k, k, generator=g) * 0.1 - 3).to(dev)
+        x = torch.randn(S * B, Ci, H, H, generator=g).to(dev)
+        conv, oshape = dict(stride=(st, st), padding=(pd, pd), dilation=(dl, dl), groups=grp), (Co, 1, 1)
+    mb = (torch.randn(Co, generator=g) * 0.1).to(dev) if bias else None
+    rb = (torch.randn(Co, generator=g) * 0.1 - 3).to(dev) if bias else None
+    kw = {}
+    if extras:
+        kw = dict(post_scale=(torch.rand(Co, generator=g) + 0.5).to(dev), post_shift=(torch.randn(Co, generator=g) * 0.1).to(dev),
+                  residual=torch.randn((S * B,) + oshape, generator=g).to(dev), relu=True)
+    pri = (torch.zeros_like(mu), torch.ones_like(mu), None if mb is None else torch.zeros_like(mb), None if mb is None else torch.ones_like(mb))
+    pk = F.pack_params(mu, rho)
+    L = _lib.lib()
+
+    def run(skinny, xs=x, S_=S, s0=4, res=None):
+        L.bt_debug_disable_skinny(0 if skinny else 1)
+        kk = dict(kw)
+        if res is not None:
+            kk["residual"] = res
+        try:
+            out, kl = F.fused_forward(xs, mu, rho, mb, rb, conv=conv, S=S_, shared_x=False, seed=21, call=6, layer_id=3, sample0=s0, packed=pk, priors=pri, want_kl=True,
+                                      workspace_owner="t_skinny", **kk)
+            return out, kl, L.bt_last_kernel_name().decode()
+        finally:
+            L.bt_debug_disable_skinny(0)
+    out, kl, kn = run(True)
+    assert "fused_split_skinny_kernel" in kn, kn
+    out2, kl2, _ = run(True)
+    assert torch.equal(out, out2) and torch.equal(kl, kl2), "the split-K combine must be deterministic"
+    ref, klr, kn0 = run(False)
+    assert "skinny" not in kn0, kn0
+    assert_close(out, ref, 2e-5, 2e-6, f"{name} vs {kn0}")
+    assert_close(kl, klr, 1e-6, 0, name + ".kl")
+    parts = []
+    for s in range(S):     # one sample per launch, same global ids
+        o, _, _ = run(True, xs=x[s * B:(s + 1) * B].contiguous(), S_=1, s0=4 + s, res=kw["residual"][s * B:(s + 1) * B].contiguous() if extras else None)
+        parts.append(o)
+    assert torch.equal(torch.cat(parts), out), "results must not depend on how the samples are launched"
+    eps_w = F.rng_fill_normal(21, 6, 3, 4, 0, S, mu.shape, dev).cpu()
+    eps_b = F.rng_fill_normal(21, 6, 3, 4, 1, S, (Co,), dev).cpu() if bias else None
+    nb = min(B, 16)
+    o = out.reshape((S, B) + oshape)
+    for s in range(S):
+        want = CO.reparam_fwd(x[s * B:s * B + nb].cpu(), mu.cpu(), rho.cpu(), eps_w[s], None if mb is None else mb.cpu(), None if rb is None else rb.cpu(),
+                              None if eps_b is None else eps_b[s], conv)
+        if extras:
+            shp = (1, -1) + (1,) * (len(oshape) - 1)
+            want = torch.relu(want * kw["post_scale"].cpu().view(shp) + kw["post_shift"].cpu().view(shp) + kw["residual"][s * B:s * B + nb].cpu())
+        assert_close(o[s, :nb].cpu(), want, RTOL, ATOL, f"{name}[s={s}] vs C oracle")
+
+
+def test_skinny_gate_is_geometric():
+    """Wide one-pixel layers (ResNet18 layer4: 32 slices per sample) stay off the split-K kernel whatever S is; the head takes it whatever
+    S is: the flavour -- and with it the K order -- of a layer never depends on how its samples are launched."""
+    from bayesian_torch_amd import _lib
+    from bayesian_torch_amd import functional as F
+    dev = torch.device("cuda")
+    L = _lib.lib()
+    for (Ci, Co, want) in ((512, 512, False), (512, 10, True)):
+        mu, rho = torch.randn(Co, Ci, 1, 1, device=dev) * 0.1, torch.randn(Co, Ci, 1, 1, device=dev) * 0.1 - 3
+        pk = F.pack_params(mu, rho)
+        for S in (1, 3, 32):
+            x = torch.randn(S * 128, Ci, 1, 1, device=dev)
+            F.fused_forward(x, mu, rho, conv=dict(stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1), S=S, shared_x=False, seed=1, call=0, layer_id=1, packed=pk,
+                            workspace_owner="t_skinny_gate")
+            assert ("skinny" in L.bt_last_kernel_name().decode()) == want, (Ci, Co, S, L.bt_last_kernel_name().decode())
