@@ -42,37 +42,80 @@ def _grads(x, w, g, conv, need_x=True):
 BACKWARD_IMPL = "hip"     # "aten": the materialising checker path below (tests only)
 
 
+def _kl_grads_aten(mu, rho, pm, ps, g, kind):
+    """(d kl / d mu, d kl / d rho) * g of kl_div's mean over one tensor, in torch ops (checker path)."""
+    n = mu.numel()
+    sq = TF.softplus(rho)
+    if kind == "laplace":    # d/dmu E|w| = erf(mu / (sigma sqrt 2)); d/dsigma = sqrt(2/pi) exp(-mu^2 / (2 sigma^2)) - 1/sigma
+        return (torch.erf(mu / (sq * 1.4142135623730951)) * (g / n),
+                (0.7978845608028654 * torch.exp(-mu * mu / (2 * sq * sq)) - 1.0 / sq) * torch.sigmoid(rho) * (g / n))
+    return (mu - pm) / (ps * ps) * (g / n), (sq / (ps * ps) - 1.0 / sq) * torch.sigmoid(rho) * (g / n)
+
+
 class FusedForward(torch.autograd.Function):
     """out[S*B, ...] = fused stochastic forward; differentiable in x, mu_w, rho_w, mu_b, rho_b."""
 
     @staticmethod
     def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, opts):
+        """opts["kl"] = (prior_mu_w, prior_sigma_w, prior_mu_b, prior_sigma_b, kind): the layer's KL term rides along -- computed by
+        the forward kernel's fused sweep, returned as a second differentiable output, and differentiated inside wgrad's finishing
+        pass (bt_conv2d_bwd_kl): a training step then has no KL launches and no KL-gradient tensors for autograd to add.
+        opts["kl_stub"]: the second output is a placeholder -- at ONE sample a layer's launch has a handful of workgroups and the fused
+        sweep of its parameters would sit on their critical path (ResNet18 step: 3.6 -> 4.6 ms), so the value is computed by one
+        bt_kl_normal launch over the whole model (KLValue below) whose backward hands every placeholder the upstream gradient.
+        opts["defer"] (a list; mc.TrainGraph): the weight gradients are computed on a side stream beside the dgrad chain and handed
+        over through the list -- (layer, dmu, drho) -- instead of through autograd; ``mc.finish_deferred`` joins and assigns them."""
         o = dict(opts)
-        out, _ = F.fused_forward(x, mu_w, rho_w, mu_b, rho_b, flip=o["flip"], conv=o["conv"], S=o["S"], shared_x=o["shared"],
-                                 seed=o["seed"], call=o["call"], layer_id=o["layer_id"], sample0=o["sample0"],
-                                 eps_w=o.get("eps_w"), eps_b=o.get("eps_b"), sign_in=o.get("sign_in"), sign_out=o.get("sign_out"),
-                                 packed=o.get("packed"), workspace_owner=("layer", o["layer_id"]), call_base=o.get("call_base"))
+        klo = o.get("kl")
+        stub = klo is not None and bool(o.get("kl_stub"))
+        out, kl = F.fused_forward(x, mu_w, rho_w, mu_b, rho_b, flip=o["flip"], conv=o["conv"], S=o["S"], shared_x=o["shared"],
+                                  seed=o["seed"], call=o["call"], layer_id=o["layer_id"], sample0=o["sample0"],
+                                  eps_w=o.get("eps_w"), eps_b=o.get("eps_b"), sign_in=o.get("sign_in"), sign_out=o.get("sign_out"),
+                                  packed=o.get("packed"), workspace_owner=o.get("workspace_owner", ("layer", o["layer_id"])), call_base=o.get("call_base"),
+                                  priors=None if (klo is None or stub) else tuple(klo[:4]), want_kl=klo is not None and not stub,
+                                  prior_type="normal" if klo is None else klo[4])
+        if stub:      # the VALUE comes from one launch over the whole model (KLValue, get_kl_loss); this output only routes its gradient here
+            kl = out.new_empty(())
         ctx.o = o
         ctx.save_for_backward(x, mu_w, rho_w, mu_b, rho_b)
         ctx.out_shape = tuple(out.shape)
-        return out
+        ctx.set_materialize_grads(False)
+        return out if klo is None else (out, kl)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_kl=None):
         x, mu_w, rho_w, mu_b, rho_b = ctx.saved_tensors
         o = ctx.o
         S, shared, conv, flip = o["S"], o["shared"], o["conv"], o["flip"]
         dev = x.device
-        g = g.contiguous()
+        g = torch.zeros(ctx.out_shape, dtype=torch.float32, device=dev) if g is None else g.contiguous()
         B = x.shape[0] // (1 if shared else S)
         coords = (o["seed"], o["call"], o["layer_id"], o["sample0"])
+        klo = o.get("kl") if g_kl is not None else None
+        lap = klo is not None and klo[4] == "laplace"
         if BACKWARD_IMPL == "hip":
             need_x = ctx.needs_input_grad[0]
             need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
             packed = o.get("packed") or F.pack_params(mu_w.detach(), rho_w.detach())
-            gx, gmu, grho = F.fused_backward(x, g, mu_w.detach(), rho_w, packed, flip=flip, conv=conv, S=S, shared_x=shared, need_x=need_x, need_w=need_w,
-                                             eps_w=o.get("eps_w"), sign_in=o.get("sign_in"), sign_out=o.get("sign_out"),
-                                             seed=o["seed"], call=o["call"], layer_id=o["layer_id"], sample0=o["sample0"], call_base=o.get("call_base"))
+            kw = dict(flip=flip, conv=conv, S=S, shared_x=shared, eps_w=o.get("eps_w"), sign_in=o.get("sign_in"), sign_out=o.get("sign_out"),
+                      seed=o["seed"], call=o["call"], layer_id=o["layer_id"], sample0=o["sample0"], call_base=o.get("call_base"))
+            kl_arg = None if klo is None else (g_kl, klo[0], klo[1], klo[4])
+            defer = o.get("defer")
+            if defer is not None and need_w:
+                # wgrad (+ its finishing pass, + the KL term) on the side stream, forked HERE -- g is ready, the dgrad below is not waited for
+                from .mc import _side_stream
+                cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    _, gmu, grho = F.fused_backward(x, g, mu_w.detach(), rho_w, packed, need_x=False, need_w=True, kl=kl_arg, **kw)
+                for t in (x, g, g_kl, packed[0], packed[1]):
+                    if t is not None:
+                        t.record_stream(side)
+                defer.append((o["layer"], gmu, grho, dev))
+                gmu = grho = None
+                gx = F.fused_backward(x, g, mu_w.detach(), rho_w, packed, need_x=True, need_w=False, **kw)[0] if need_x else None
+            else:
+                gx, gmu, grho = F.fused_backward(x, g, mu_w.detach(), rho_w, packed, need_x=need_x, need_w=need_w, kl=kl_arg, **kw)
             gmu_b = grho_b = None
             if mu_b is not None:
                 Co = mu_w.shape[0]
@@ -89,6 +132,9 @@ class FusedForward(torch.autograd.Function):
                     eps_b = F.rng_fill_normal(*coords, 1, S, (Co,), dev, call_base=o.get("call_base"))
                 gmu_b = gs.sum((0, 1, 3))
                 grho_b = (gp * eps_b.reshape(S, Co)).sum(0) * torch.sigmoid(rho_b)
+                if klo is not None:      # the bias term of the layer's KL (bias-sized: its own small launch)
+                    km, kr = F.kl_backward(mu_b, rho_b, klo[2], klo[3], g_kl, laplace=lap)
+                    gmu_b, grho_b = gmu_b + km, grho_b + kr
             return gx, gmu, grho, gmu_b, grho_b, None
         if o.get("call_base") is not None:
             raise RuntimeError("the ATen checker path does not replay graph-captured draws")
@@ -147,6 +193,12 @@ class FusedForward(torch.autograd.Function):
                     gx += gxs
                 else:
                     gx[s * B:(s + 1) * B] = gxs
+        if klo is not None:
+            km, kr = _kl_grads_aten(mu_w, rho_w, klo[0], klo[1], g_kl, klo[4])
+            gmu, grho = gmu + km, grho + kr
+            if has_b:
+                km, kr = _kl_grads_aten(mu_b, rho_b, klo[2], klo[3], g_kl, klo[4])
+                gmu_b, grho_b = gmu_b + km, grho_b + kr
         return gx, gmu, grho, gmu_b, grho_b, None
 
 
@@ -172,13 +224,22 @@ class KLNormal(torch.autograd.Function):
             return tuple(grads)
         for i in range(0, len(t), 4):
             mu, rho, pm, ps = t[i:i + 4]
-            n = mu.numel()
-            sq = TF.softplus(rho)
-            if ctx.kind == "laplace":    # d/dmu E|w| = erf(mu / (sigma sqrt 2)); d/dsigma = sqrt(2/pi) exp(-mu^2 / (2 sigma^2)) - 1/sigma
-                gmu = torch.erf(mu / (sq * 1.4142135623730951)) * (g / n)
-                grho = (0.7978845608028654 * torch.exp(-mu * mu / (2 * sq * sq)) - 1.0 / sq) * torch.sigmoid(rho) * (g / n)
-            else:
-                gmu = (mu - pm) / (ps * ps) * (g / n)
-                grho = (sq / (ps * ps) - 1.0 / sq) * torch.sigmoid(rho) * (g / n)
+            gmu, grho = _kl_grads_aten(mu, rho, pm, ps, g, ctx.kind)
             grads += [gmu, grho, None, None]
         return tuple(grads)
+
+
+class KLValue(torch.autograd.Function):
+    """get_kl_loss of a training step whose layers differentiate their own KL terms (FusedForward, opts["kl"] + opts["kl_stub"]):
+    the value from ONE bt_kl_normal launch over all segments; backward gives the upstream gradient to every layer's placeholder --
+    the layers' weight-gradient passes do the rest (bt_conv2d_bwd_kl). No KL-gradient tensors, no second sweep."""
+
+    @staticmethod
+    def forward(ctx, info, *stubs):
+        segs, lids, owner, laplace = info
+        ctx.n = len(stubs)
+        return _lib.kl_normal([tuple(t.detach() for t in sg) for sg in segs], layer_ids=list(lids), owner=owner, laplace=laplace)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + (g,) * ctx.n

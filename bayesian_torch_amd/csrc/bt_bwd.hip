@@ -35,6 +35,9 @@ struct BwdArgs {
   int sgroups, mchunk;              // wgrad: groups = sgroups (sample s handled by s % sgroups) x chunks of mchunk rows of M = B*Ho*Wo
   uint32_t seed_lo, seed_hi, call, layer_id, sample0;
   const uint32_t* call_base;
+  // bt_conv2d_bwd_kl: the layer's KL term differentiated in wgrad's finishing pass (all null / 0 otherwise)
+  const float *mu_w, *pmu_w, *psig_w, *gkl;
+  int kl_laplace;
 };
 
 constexpr int kBK = 16;   // reduction steps per LDS stage
@@ -263,11 +266,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const BwdArgs a) {
   }
 }
 
-// natural element (co, ci, tap) <- sum over the groups' partials at the tap-major position, in group order
+// (dKL/dmu, dKL/drho) of ONE element of kl_div's mean (base_variational_layer.py:70-72; 'laplace': :74-97), times gs = upstream / n.
+// The op order of kl_normal_bwd_kernel below (which calls it): a gradient built here and one built there are the same bits.
+__device__ __forceinline__ void kl_elem_grad(float m, float r, const float* pmu, const float* psig, long long i, int laplace, float gs, float& dm, float& dr) {
+  const float sq = softplus(r);
+  const float sg = __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __builtin_amdgcn_exp2f(__fmul_rn(-1.4426950408889634f, r))));
+  float gm, gq;
+  if (laplace) {  // d/dmu E|w| = erf(mu / (sq sqrt 2)); d/dsq = sqrt(2/pi) exp(-mu^2 / (2 sq^2)) - 1/sq
+    const float z = __fmul_rn(m, __builtin_amdgcn_rcpf(__fmul_rn(sq, 1.4142135623730951f)));
+    gm = erff(z);
+    gq = __fsub_rn(__fmul_rn(0.7978845608028654f, __builtin_amdgcn_exp2f(__fmul_rn(-1.4426950408889634f, __fmul_rn(z, z)))), __builtin_amdgcn_rcpf(sq));
+  } else {
+    const float ip = __builtin_amdgcn_rcpf(__fmul_rn(psig[i], psig[i]));
+    gm = __fmul_rn(__fsub_rn(m, pmu[i]), ip);
+    gq = __fsub_rn(__fmul_rn(sq, ip), __builtin_amdgcn_rcpf(sq));
+  }
+  dm = __fmul_rn(gm, gs);
+  dr = __fmul_rn(__fmul_rn(gq, sg), gs);
+}
+
+// natural element (co, ci, tap) <- sum over the groups' partials at the tap-major position, in group order; with a.gkl also the
+// layer's KL term: grad = (contraction path) + (KL path), the sum autograd's AccumulateGrad would have made of the two tensors.
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const BwdArgs a) {
   const long long n = (long long)a.Co * a.Cig * a.T;
   const int KP = a.T * a.Cig4;
   const long long plane = (long long)a.Co * KP;
+  const float gkl_s = a.gkl ? a.gkl[0] / (float)n : 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const int tap = (int)(i % a.T);
     const long long rc = i / a.T;
@@ -275,11 +299,16 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const BwdArgs a) {
     const long long o = (long long)co * KP + (long long)tap * a.Cig4 + ci;
     float sm = 0.f, sr = 0.f;
     for (int gq = 0; gq < a.groups; ++gq) sm = __fadd_rn(sm, a.part[gq * plane + o]), sr = __fadd_rn(sr, a.part[(a.groups + gq) * plane + o]);
-    if (a.dmu) a.dmu[i] = sm;
-    if (a.drho) {
-      const float sg = __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __builtin_amdgcn_exp2f(__fmul_rn(-1.4426950408889634f, a.rho_w[i]))));  // sigmoid(rho)
-      a.drho[i] = __fmul_rn(sr, sg);
+    const float r = a.rho_w[i];
+    const float sg = __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __builtin_amdgcn_exp2f(__fmul_rn(-1.4426950408889634f, r))));  // sigmoid(rho)
+    float om = sm, orr = __fmul_rn(sr, sg);
+    if (a.gkl) {
+      float km, kr;
+      kl_elem_grad(a.mu_w[i], r, a.pmu_w, a.psig_w, i, a.kl_laplace, gkl_s, km, kr);
+      om = __fadd_rn(om, km), orr = __fadd_rn(orr, kr);
     }
+    if (a.dmu) a.dmu[i] = om;
+    if (a.drho) a.drho[i] = orr;
   }
 }
 
@@ -289,20 +318,7 @@ __global__ __launch_bounds__(256) void kl_normal_bwd_kernel(const float* __restr
                                                             float* __restrict__ dmu, float* __restrict__ drho) {
   const float gs = gup[0] / (float)n;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const float m = mu[i], r = rho[i], sq = softplus(r);
-    const float sg = __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __builtin_amdgcn_exp2f(__fmul_rn(-1.4426950408889634f, r))));
-    float gm, gq;
-    if (laplace) {  // d/dmu E|w| = erf(mu / (sq sqrt 2)); d/dsq = sqrt(2/pi) exp(-mu^2 / (2 sq^2)) - 1/sq
-      const float z = __fmul_rn(m, __builtin_amdgcn_rcpf(__fmul_rn(sq, 1.4142135623730951f)));
-      gm = erff(z);
-      gq = __fsub_rn(__fmul_rn(0.7978845608028654f, __builtin_amdgcn_exp2f(__fmul_rn(-1.4426950408889634f, __fmul_rn(z, z)))), __builtin_amdgcn_rcpf(sq));
-    } else {
-      const float ip = __builtin_amdgcn_rcpf(__fmul_rn(psig[i], psig[i]));
-      gm = __fmul_rn(__fsub_rn(m, pmu[i]), ip);
-      gq = __fsub_rn(__fmul_rn(sq, ip), __builtin_amdgcn_rcpf(sq));
-    }
-    dmu[i] = __fmul_rn(gm, gs);
-    drho[i] = __fmul_rn(__fmul_rn(gq, sg), gs);
+    kl_elem_grad(mu[i], rho[i], pmu, psig, i, laplace, gs, dmu[i], drho[i]);
   }
 }
 
@@ -395,11 +411,16 @@ extern "C" size_t bt_conv2d_bwd_workspace(const bt_conv2d_geom* g, int32_t S) {
   return wg > dg ? wg : dg;
 }
 
-extern "C" int bt_conv2d_bwd(const bt_conv2d_geom* g, int32_t S, int32_t flipout, const float* x, int64_t x_sample_stride, const float* grad_out,
-                             const bt_params* p, const bt_draws* d, float* dx, float* dmu_w, float* drho_w, void* workspace, size_t workspace_bytes,
-                             bt_stream_t stream) {
+static int conv2d_bwd_impl(const bt_conv2d_geom* g, int32_t S, int32_t flipout, const float* x, int64_t x_sample_stride, const float* grad_out,
+                           const bt_params* p, const bt_draws* d, const float* grad_kl, float* dx, float* dmu_w, float* drho_w, void* workspace,
+                           size_t workspace_bytes, bt_stream_t stream) {
   using namespace bt;
   if (!g || !x || !grad_out || !p || !d) return set_error(BT_ERR_BAD_ARG, "bt_conv2d_bwd: null argument");
+  if (grad_kl) {
+    const bool lap = p->prior_kind == BT_PRIOR_LAPLACE;
+    if (!dmu_w) return set_error(BT_ERR_BAD_ARG, "bt_conv2d_bwd_kl: grad_kl needs dmu_w / drho_w");
+    if (!p->mu_w || (!lap && (!p->prior_mu_w || !p->prior_sigma_w))) return set_error(BT_ERR_BAD_ARG, "bt_conv2d_bwd_kl: needs mu_w and the weight priors");
+  }
   if (!p->mu_packed || !p->sigma_packed || !p->rho_w) return set_error(BT_ERR_BAD_ARG, "bt_conv2d_bwd: needs rho_w and the packed parameters (bt_pack_params)");
   if (S <= 0 || g->B <= 0 || g->Ci <= 0 || g->Co <= 0 || g->groups <= 0 || g->Ci % g->groups || g->Co % g->groups) return set_error(BT_ERR_BAD_ARG, "bt_conv2d_bwd: bad geometry");
   if ((dmu_w == nullptr) != (drho_w == nullptr)) return set_error(BT_ERR_BAD_ARG, "bt_conv2d_bwd: dmu_w and drho_w go together");
@@ -409,6 +430,7 @@ extern "C" int bt_conv2d_bwd(const bt_conv2d_geom* g, int32_t S, int32_t flipout
   a.x = x, a.g = grad_out, a.mu_pk = p->mu_packed, a.sig_pk = p->sigma_packed, a.rho_w = p->rho_w;
   a.eps_w = d->eps_w, a.sign_in = flipout ? d->sign_in : nullptr, a.sign_out = flipout ? d->sign_out : nullptr;
   a.dx = dx, a.dmu = dmu_w, a.drho = drho_w, a.part = (float*)workspace;
+  if (grad_kl) a.gkl = grad_kl, a.mu_w = p->mu_w, a.pmu_w = p->prior_mu_w, a.psig_w = p->prior_sigma_w, a.kl_laplace = p->prior_kind == BT_PRIOR_LAPLACE ? 1 : 0;
   a.B = g->B, a.Ci = g->Ci, a.H = g->H, a.W = g->W, a.Co = g->Co, a.KH = g->kh, a.KW = g->kw;
   a.SH = g->sh, a.SW = g->sw, a.PH = g->ph, a.PW = g->pw, a.DH = g->dh, a.DW = g->dw, a.G = g->groups;
   a.Ho = (g->H + 2 * g->ph - g->dh * (g->kh - 1) - 1) / g->sh + 1;
@@ -450,6 +472,18 @@ extern "C" int bt_conv2d_bwd(const bt_conv2d_geom* g, int32_t S, int32_t flipout
     if (int rc = check_launch("bt_conv2d_bwd (finish)")) return rc;
   }
   return BT_OK;
+}
+
+extern "C" int bt_conv2d_bwd(const bt_conv2d_geom* g, int32_t S, int32_t flipout, const float* x, int64_t x_sample_stride, const float* grad_out,
+                             const bt_params* p, const bt_draws* d, float* dx, float* dmu_w, float* drho_w, void* workspace, size_t workspace_bytes,
+                             bt_stream_t stream) {
+  return conv2d_bwd_impl(g, S, flipout, x, x_sample_stride, grad_out, p, d, nullptr, dx, dmu_w, drho_w, workspace, workspace_bytes, stream);
+}
+
+extern "C" int bt_conv2d_bwd_kl(const bt_conv2d_geom* g, int32_t S, int32_t flipout, const float* x, int64_t x_sample_stride, const float* grad_out,
+                                const bt_params* p, const bt_draws* d, const float* grad_kl, float* dx, float* dmu_w, float* drho_w, void* workspace,
+                                size_t workspace_bytes, bt_stream_t stream) {
+  return conv2d_bwd_impl(g, S, flipout, x, x_sample_stride, grad_out, p, d, grad_kl, dx, dmu_w, drho_w, workspace, workspace_bytes, stream);
 }
 
 extern "C" int bt_kl_normal_bwd(const float* mu, const float* rho, const float* prior_mu, const float* prior_sigma, const float* grad_kl, int64_t numel,

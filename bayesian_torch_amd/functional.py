@@ -211,10 +211,12 @@ def mc_epilogue(logits):
 
 
 def fused_backward(x, grad_out, mu_w, rho_w, packed, *, flip=False, conv=None, S=1, shared_x=True, need_x=True, need_w=True,
-                   eps_w=None, sign_in=None, sign_out=None, seed=0, call=0, layer_id=0, sample0=0, call_base=None):
+                   eps_w=None, sign_in=None, sign_out=None, seed=0, call=0, layer_id=0, sample0=0, call_base=None, kl=None):
     """Gradients of ``fused_forward`` on the HIP backward kernels (bt_conv2d_bwd): the draws are regenerated on chip from the
     forward's RNG coordinates (or the injected ones are read).  x / grad_out as the forward saw / produced them.
-    -> (dx like x or None, dmu_w, drho_w like mu_w or None).  Bias gradients are row sums of grad_out (caller)."""
+    -> (dx like x or None, dmu_w, drho_w like mu_w or None).  Bias gradients are row sums of grad_out (caller).
+    ``kl = (grad_kl device scalar, prior_mu_w, prior_sigma_w, prior kind)``: the layer's weight-KL term is differentiated in the same
+    pass and added to dmu_w / drho_w (bt_conv2d_bwd_kl)."""
     x, g = _lib.dev_f32(x, "input"), _lib.dev_f32(grad_out, "grad_out")
     dev = x.device
     mu_w, rho_w = _lib.dev_f32(mu_w, "mu_w"), _lib.dev_f32(rho_w.detach(), "rho_w")
@@ -233,12 +235,18 @@ def fused_backward(x, grad_out, mu_w, rho_w, packed, *, flip=False, conv=None, S
     # partials of wgrad's sample / reduction groups and of dgrad's output-channel pieces (contents need not be initialised)
     ws = torch.empty(max(16, L.bt_conv2d_bwd_workspace(C.byref(geom), S)), dtype=torch.uint8, device=dev)
     inj = [None if t is None else _lib.dev_f32(t, "draw") for t in (eps_w, sign_in, sign_out)]
-    P = _lib.bt_params(mu_w.data_ptr(), rho_w.data_ptr(), None, None, None, None, None, None, packed[0].data_ptr(), packed[1].data_ptr(), 0, 0)
+    gkl = pm = ps = None
+    lap = 0
+    if kl is not None and need_w:
+        gkl = _lib.dev_f32(kl[0].reshape(1), "grad_kl")
+        lap = 1 if kl[3] == "laplace" else 0
+        pm, ps = (None, None) if lap else (_lib.dev_f32(kl[1], "prior_mu"), _lib.dev_f32(kl[2], "prior_sigma"))
+    P = _lib.bt_params(mu_w.data_ptr(), rho_w.data_ptr(), None, None, _lib.ptr(pm), _lib.ptr(ps), None, None, packed[0].data_ptr(), packed[1].data_ptr(), lap, 0)
     R = _rng(seed, call, layer_id, sample0, call_base)     # call_base: the device word of a captured training step (mc.TrainGraph)
     D = _lib.bt_draws(_lib.ptr(inj[0]), None, _lib.ptr(inj[1]), _lib.ptr(inj[2]), R)
     with _lib.on(dev):
-        _lib.check(L.bt_conv2d_bwd(C.byref(geom), S, 1 if flip else 0, x.data_ptr(), 0 if shared_x else x_elems, g.data_ptr(), C.byref(P), C.byref(D),
-                                   _lib.ptr(dx), _lib.ptr(dmu), _lib.ptr(drho), _lib.ptr(ws), 0 if ws is None else ws.numel(), _lib.stream_ptr(dev)))
+        _lib.check(L.bt_conv2d_bwd_kl(C.byref(geom), S, 1 if flip else 0, x.data_ptr(), 0 if shared_x else x_elems, g.data_ptr(), C.byref(P), C.byref(D), _lib.ptr(gkl),
+                                      _lib.ptr(dx), _lib.ptr(dmu), _lib.ptr(drho), _lib.ptr(ws), 0 if ws is None else ws.numel(), _lib.stream_ptr(dev)))
     if need_x:
         dx = dx.sum(0) if shared_x else dx.reshape(x.shape)
     return dx, dmu, drho

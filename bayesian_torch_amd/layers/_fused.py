@@ -109,7 +109,25 @@ class FusedBayesLayer(BaseVariationalLayer_):
     def _prior_kind(self):
         return check_prior_type(getattr(self, "prior_type", "normal"))
 
+    def _param_versions(self):
+        return tuple(t._version for sg in self._kl_segments() for t in sg[:2])
+
+    def _take_live_kl(self):
+        """The differentiable KL tensor the last training forward produced (FusedForward's second output), once, and only while the
+        parameters are the ones it was computed from; else None (the caller launches the KL kernel)."""
+        live, self._kl_live = getattr(self, "_kl_live", None), None
+        if live is None or not torch.is_grad_enabled() or live[1] != self._param_versions():
+            return None
+        return live
+
     def kl_loss(self):
+        live = self._take_live_kl()
+        if live is not None:
+            if not live[2]:
+                return live[0]
+            from ..autograd import KLValue      # a placeholder (training step at one sample): the value from this layer's own launch
+            segs = self._kl_segments()
+            return KLValue.apply((segs, [0] * len(segs), ("layer", self._ws_id), self._prior_kind() == "laplace"), live[0])
         kind = self._prior_kind()
         segs = self._kl_segments()
         if torch.is_grad_enabled() and any(t.requires_grad for sg in segs for t in sg):
@@ -235,12 +253,23 @@ class FusedBayesLayer(BaseVariationalLayer_):
             from ..autograd import FusedForward, KLNormal
             opts = dict(flip=self._flip, conv=conv, S=S, shared=shared, seed=seed, call=call, layer_id=self._layer_id, sample0=sample0,
                         eps_w=draw.get("eps_w"), eps_b=draw.get("eps_b"), sign_in=draw.get("sign_in"), sign_out=draw.get("sign_out"),
-                        packed=self._packed(), call_base=call_base)     # call_base: a captured training step (mc.TrainGraph)
-            out = FusedForward.apply(x, mu_t, rho_t, self.mu_bias, self.rho_bias, opts)
-            kl = None
-            if want_kl:
-                flat = [t for sg in self._kl_segments() for t in sg]
-                kl = KLNormal.apply((("layer", self._ws_id), kind), *flat)
+                        packed=self._packed(), call_base=call_base,      # call_base: a captured training step (mc.TrainGraph)
+                        workspace_owner=("layer", self._ws_id))
+            fused_kl = ctx is not None and getattr(ctx, "train_fused", False)
+            if fused_kl:
+                # a training step (mc.TrainGraph): the KL term comes out of the forward kernel's fused sweep and is differentiated in
+                # wgrad's finishing pass; get_kl_loss() / kl_loss() pick the live tensor up instead of launching a KL kernel
+                opts["kl"] = (self.prior_weight_mu, self.prior_weight_sigma, self.prior_bias_mu, self.prior_bias_sigma, self._prior_kind())
+                opts["defer"], opts["layer"] = ctx.deferred, self
+                opts["kl_stub"] = not want_kl       # nobody reads this layer's KL by itself: one launch per model computes the value
+                out, kl = FusedForward.apply(x, mu_t, rho_t, self.mu_bias, self.rho_bias, opts)
+                self._kl_live = (kl, self._param_versions(), opts["kl_stub"])
+            else:
+                out = FusedForward.apply(x, mu_t, rho_t, self.mu_bias, self.rho_bias, opts)
+                kl = None
+                if want_kl:
+                    flat = [t for sg in self._kl_segments() for t in sg]
+                    kl = KLNormal.apply((("layer", self._ws_id), kind), *flat)
         else:
             priors = (self.prior_weight_mu, self.prior_weight_sigma, self.prior_bias_mu, self.prior_bias_sigma) if want_kl else None
             out, kl = F.fused_forward(x, mu_t, rho_t, self.mu_bias, self.rho_bias, flip=self._flip, conv=conv,

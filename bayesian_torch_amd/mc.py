@@ -26,6 +26,8 @@ class McContext:
         self.synced = set()      # id() of the layers whose packs sync_model_packs has verified inside this context
         self.pack_event = None   # recorded on the side stream that verifies every layer but the first (sync_model_packs)
         self.late = set()        # id() of the layers verified there: the first of them to run makes the launch stream wait
+        self.train_fused = False  # TrainGraph: forwards carry their KL term along (FusedForward's second output) ...
+        self.deferred = None     # ... and (a list) hand their weight gradients over here, computed on the side stream: (layer, dmu, drho, device)
 
 
 def current():
@@ -170,6 +172,26 @@ class McGraph:
         return self.logits, self.kl, self.packed
 
 
+def finish_deferred(ctx):
+    """Join the side stream that computed the deferred weight gradients of a training step (autograd.FusedForward, opts["defer"]) and
+    give them to their parameters -- ``p.grad`` exactly as autograd would have left it: assigned, or added to what is there."""
+    if not ctx.deferred:
+        return
+    devs = {d for (_, _, _, d) in ctx.deferred}
+    for dev in devs:
+        torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+    for layer, gmu, grho, dev in ctx.deferred:
+        cur = torch.cuda.current_stream(dev)
+        for p, g in ((layer._w("mu"), gmu), (layer._w("rho"), grho)):
+            g = g.view_as(p)
+            g.record_stream(cur)
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+    ctx.deferred.clear()
+
+
 class TrainGraph:
     """One TRAINING step -- zero_grad, forward (fused kernels, one MC sample), ``loss_fn(model, out, y)``, backward (HIP dgrad /
     wgrad with the draws regenerated on chip), optimizer step -- captured once in a HIP graph and replayed per batch: the ~400
@@ -180,8 +202,15 @@ class TrainGraph:
     ``lambda m, out, y: cross_entropy(out, y) + get_kl_loss(m) / batch`` (reference loop:
     examples/main_bayesian_cifar_dnn2bnn.py:402-420)."""
 
-    def __init__(self, model, optimizer, loss_fn, x, y, warmup=3):
+    def __init__(self, model, optimizer, loss_fn, x, y, warmup=3, fused=True, side_wgrad=None):
+        """fused=True: every layer's KL term comes out of its forward kernel and is differentiated inside its weight-gradient pass
+        (no KL launches, no KL-gradient tensors), and the weight-gradient passes run on a side stream -- a parallel branch of the
+        captured graph -- beside the data-gradient chain. fused=False: plain autograd wiring (the checker the tests compare with)."""
         from . import rng
+        import os
+        if side_wgrad is None:
+            side_wgrad = os.environ.get("BT_TRAIN_SIDE_WGRAD", "0") not in ("", "0")
+        side_wgrad = bool(side_wgrad and fused)
         self.x, self.y = x.clone(), y.clone()
         self.call_base = torch.zeros(1, dtype=torch.int32, device=x.device)
         B = x.shape[0]
@@ -189,6 +218,7 @@ class TrainGraph:
         def run():
             optimizer.zero_grad(set_to_none=True)
             with mc_samples(1, B, 0, collect_kl=False, call_base=self.call_base) as ctx:
+                ctx.train_fused, ctx.deferred = fused, ([] if side_wgrad else None)
                 # the optimizer step of the previous replay changed every parameter: one check + rebuild per model, in the launch stream
                 # (beside a one-sample stem there is nothing to hide the rebuild behind: the forked form measured 6 % slower here)
                 sync_model_packs(model, ctx, overlap=False)
@@ -197,6 +227,7 @@ class TrainGraph:
             out = out[0] if isinstance(out, tuple) else out
             loss = loss_fn(model, out, self.y)
             loss.backward()
+            finish_deferred(ctx)
             optimizer.step()
             return loss.detach()
 

@@ -79,6 +79,31 @@ def dnn_to_bnn(m, bnn_prior_parameters):
 
 def get_kl_loss(m):
     """Sum of ``layer.kl_loss()`` over every module that has one; None without Bayesian layers."""
+    import torch
+    fused = [layer for layer in m.modules() if isinstance(layer, FusedBayesLayer)]
+    if fused and torch.is_grad_enabled() and all(getattr(layer, "_kl_live", None) is not None for layer in fused):
+        # a training step whose forwards carried their KL terms along (mc.TrainGraph): no KL launch, one stack + sum
+        live = [layer._take_live_kl() for layer in fused]
+        if all(k is not None for k in live):
+            from ..autograd import KLValue
+            vals = [k[0] for k in live if not k[2]]                 # values out of the forward kernels' fused sweeps
+            kl = torch.stack(vals).sum() if vals else None
+            by_kind = {}
+            for layer, k in zip(fused, live):                      # placeholders: ONE launch per prior kind computes their value
+                if k[2]:
+                    by_kind.setdefault(layer._prior_kind() == "laplace", []).append((layer, k[0]))
+            for lap, items in by_kind.items():
+                segs, lids = [], []
+                for i, (layer, _) in enumerate(items):
+                    sg = layer._kl_segments()
+                    segs += sg
+                    lids += [i] * len(sg)
+                v = KLValue.apply((segs, lids, ("model", id(m), lap), lap), *[st for _, st in items])
+                kl = v if kl is None else kl + v
+            for layer in m.modules():
+                if not isinstance(layer, FusedBayesLayer) and hasattr(layer, "kl_loss"):
+                    kl = kl + layer.kl_loss()
+            return kl
     segs, lids, others, lap = [], [], [], []
     n = 0
     for layer in m.modules():

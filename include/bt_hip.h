@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BT_VERSION 300
+#define BT_VERSION 301
 #define BT_WORKSPACE_BYTES 65536
 
 #define BT_OK 0
@@ -238,6 +238,16 @@ size_t bt_conv2d_bwd_workspace(const bt_conv2d_geom *g, int32_t S);
 int bt_conv2d_bwd(const bt_conv2d_geom *g, int32_t S, int32_t flipout, const float *x, int64_t x_sample_stride, const float *grad_out,
                   const bt_params *p, const bt_draws *d, float *dx, float *dmu_w, float *drho_w,
                   void *workspace, size_t workspace_bytes, bt_stream_t stream);
+/* bt_conv2d_bwd with the layer's KL term differentiated in the same pass (a training step's loss holds both: the reference adds
+ * get_kl_loss(model) / batch to the criterion, examples/main_bayesian_cifar_dnn2bnn.py:402-420): grad_kl = device scalar, the
+ * upstream gradient of THIS layer's weight-KL mean (base_variational_layer.py:70-72; p->prior_kind selects :74-97). Then
+ *   dmu_w[i] += grad_kl[0] / n * dKL_i/dmu,  drho_w[i] += grad_kl[0] / n * dKL_i/drho   (n = elements of mu_w)
+ * in the op order autograd would add bt_kl_normal_bwd's tensors to bt_conv2d_bwd's: same bits, no second sweep, no KL-gradient
+ * tensors. p additionally needs mu_w and (normal prior) prior_mu_w / prior_sigma_w. grad_kl NULL = bt_conv2d_bwd. Bias KL
+ * gradients (bias-sized) stay with the caller. */
+int bt_conv2d_bwd_kl(const bt_conv2d_geom *g, int32_t S, int32_t flipout, const float *x, int64_t x_sample_stride, const float *grad_out,
+                     const bt_params *p, const bt_draws *d, const float *grad_kl, float *dx, float *dmu_w, float *drho_w,
+                     void *workspace, size_t workspace_bytes, bt_stream_t stream);
 /* Gradient of bt_kl_normal's mean over ONE tensor: dmu[i], drho[i] = d kl / d(mu_i, rho_i) * grad_kl[0] (grad_kl: device
  * scalar); flags: BT_KL_PRIOR_LAPLACE for the 'laplace' branch (priors unused then). */
 int bt_kl_normal_bwd(const float *mu, const float *rho, const float *prior_mu, const float *prior_sigma, const float *grad_kl,

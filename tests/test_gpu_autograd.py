@@ -130,10 +130,16 @@ def test_hip_backward_equals_the_materialising_checker():
         assert_close(grads["hip"][n].cpu(), grads["aten"][n].cpu(), 2e-4, 2e-5, n)
 
 
-def test_train_graph_replays_the_eager_training_loop():
+@pytest.mark.parametrize("fused", [False, True])
+def test_train_graph_replays_the_eager_training_loop(fused):
     """mc.TrainGraph (one training step in a HIP graph; forward and backward kernels add the device word call_base to their call
     coordinate) against the same loop run eagerly from the same RNG position: same parameters after the same number of steps,
-    bit for bit -- the replayed backward regenerates the draws of ITS forward, and every kernel sums in a fixed order."""
+    bit for bit -- the replayed backward regenerates the draws of ITS forward, and every kernel sums in a fixed order.
+    fused=True (the default wiring): the KL terms come out of the forward kernels and are differentiated inside the weight-gradient
+    passes (bt_conv2d_bwd_kl), which run on a side stream beside the data-gradient chain -- the PARAMETERS still match the plain
+    autograd loop bit for bit (the same gradient bits: contraction path + KL path added in one kernel instead of by AccumulateGrad);
+    the loss VALUE adds the per-layer KL means in a different order (21 fp32 values stacked and summed instead of one kernel's
+    sum), so it is held to 1e-6 relative."""
     import copy
     from bayesian_torch_amd import rng
     from bayesian_torch_amd.harness import resnet as H
@@ -163,9 +169,13 @@ def test_train_graph_replays_the_eager_training_loop():
 
     rng.manual_seed(11)
     opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
-    tg = TrainGraph(net, opt, loss_fn, x, y, warmup=n_warm)        # n_warm real steps, eager
+    tg = TrainGraph(net, opt, loss_fn, x, y, warmup=n_warm, fused=fused)        # n_warm real steps, eager
     graph_losses = [float(tg.step()) for _ in range(n_steps)]
-    assert graph_losses == eager_losses[n_warm:], (graph_losses, eager_losses)
+    if fused:
+        for a, b in zip(graph_losses, eager_losses[n_warm:]):
+            assert abs(a - b) <= 1e-6 * abs(b), (graph_losses, eager_losses)
+    else:
+        assert graph_losses == eager_losses[n_warm:], (graph_losses, eager_losses)
     for (k, a), (_, b) in zip(net.state_dict().items(), ref.state_dict().items()):
         assert torch.equal(a, b), k
     assert len(set(graph_losses)) == n_steps       # fresh draws every replay

@@ -443,3 +443,61 @@ def test_skinny_gate_is_geometric():
             F.fused_forward(x, mu, rho, conv=dict(stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1), S=S, shared_x=False, seed=1, call=0, layer_id=1, packed=pk,
                             workspace_owner="t_skinny_gate")
             assert ("skinny" in L.bt_last_kernel_name().decode()) == want, (Ci, Co, S, L.bt_last_kernel_name().decode())
+
+
+@pytest.mark.parametrize("case", ["conv normal prior", "conv laplace prior + bias", "flipout conv + bias", "linear + bias, S=3", "deferred to the side stream"])
+def test_kl_term_differentiated_inside_wgrad_equals_autograd_sum(case):
+    """bt_conv2d_bwd_kl / FusedForward(opts["kl"]): the layer's KL comes out of the forward kernel as a second differentiable output and
+    its gradient is added inside wgrad's finishing pass. Against the plain wiring (FusedForward + KLNormal, autograd adds the two
+    gradient tensors) on the same draws: the same bits for every gradient, the same KL value as the fused inference sweep; and
+    against the materialising ATen checker at its tolerance. "deferred": the weight gradients computed on the side stream and
+    handed over by mc.finish_deferred."""
+    import bayesian_torch_amd.autograd as AG
+    import bayesian_torch_amd.layers as L
+    from bayesian_torch_amd import mc, rng
+    rng.set_mode("philox")
+    torch.manual_seed(3)
+    S, B = (3, 8) if "S=3" in case else (1, 16)
+    if case.startswith("linear"):
+        layer = L.LinearReparameterization(96, 40, bias=True).cuda()
+        x0 = torch.randn(B, 96).cuda()
+    elif case.startswith("flipout"):
+        layer = L.Conv2dFlipout(16, 24, 3, padding=1, bias=True).cuda()
+        x0 = torch.randn(B, 16, 6, 6).cuda()
+    else:
+        kw = dict(prior_type="laplace", bias=True) if "laplace" in case else dict(bias=False)
+        layer = L.Conv2dReparameterization(16, 24, 3, padding=1, **kw).cuda()
+        x0 = torch.randn(B, 16, 6, 6).cuda()
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    params = list(layer.parameters())
+
+    def step(fused, impl="hip", defer=False):
+        AG.BACKWARD_IMPL = impl
+        try:
+            rng.manual_seed(5)
+            for p in params:
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            with mc.mc_samples(S, B) as ctx:
+                ctx.train_fused, ctx.deferred = fused, ([] if defer else None)
+                out, kl = layer(x)
+            loss = (out * torch.linspace(-1, 1, out.numel(), device=out.device).reshape(out.shape)).sum() + kl * 0.37
+            loss.backward()
+            mc.finish_deferred(ctx)
+            torch.cuda.synchronize()
+            return kl.detach().clone(), x.grad.clone(), [p.grad.clone() for p in params]
+        finally:
+            AG.BACKWARD_IMPL = "hip"
+    kl0, gx0, g0 = step(False)
+    kl1, gx1, g1 = step(True, defer="deferred" in case)
+    assert_close(kl1, kl0, 1e-6, 0, case + ".kl")      # (the fused sweep's partial order is the forward kernel's own)
+    assert torch.equal(gx1, gx0), case
+    for (n, _), a, b in zip(layer.named_parameters(), g1, g0):
+        assert torch.equal(a, b), f"{case}: grad of {n} differs: max abs {float((a - b).abs().max()):.3e}"
+    if "deferred" not in case:
+        _, gx2, g2 = step(True, impl="aten")
+        assert_close(gx1, gx2, 2e-4, 2e-5, case + ".dx vs aten")
+        for (n, _), a, b in zip(layer.named_parameters(), g1, g2):
+            assert_close(a, b, 2e-4, 2e-5, f"{case}: grad of {n} vs aten")
