@@ -279,10 +279,12 @@ __global__ __launch_bounds__(kDirectThreads) void fused_split_direct_kernel(cons
   head_load(xr[2]);
 
   // Four K16 steps from the weight image at wq (its step 0 = the block's first step), x from the ring.
-  // (Round 3, measured: software-pipelining the split of the next unit behind the current unit's MFMAs with sched_group_barrier -- one
-  // MFMA, four VALU, ... in the emitted code -- changes nothing: 2.94 ms either way on ResNet50's layer3 conv3. PMC of that launch:
-  // matrix pipe busy 52 %, VALU busy 45 % of a shader clock that averages ~1.35 GHz of the 2.4 GHz it could run at: the launch sits at
-  // the power limit, and what it needs is fewer instructions and bytes per MFMA, not a denser schedule.)
+  // (Round 3, measured with A/B builds on one box, tools/build_variant.sh + tools/ab_direct.sh, S = 8, b256: emitting the split of item
+  // t + 1 ahead of item t's twelve MFMAs, alone or spread between them by sched_group_barrier -- one MFMA, then 4 or 8 VALU -- is 1 ... 4 %
+  // SLOWER than this plain form on ResNet50's layer3 conv3 / conv1, layer1 conv3 and the layer2 downsample (1443 / 1895 / 2241 / 3808 us
+  // here; 1485 ... 1512 / 1881 ... 1953 / 2288 ... 2378 / 3742 ... 3804 us pipelined). PMC of the conv3 launch: matrix pipe busy 52 %,
+  // VALU busy 45 % of a shader clock that averages ~1.35 GHz of the 2.4 GHz it could run at: the launch sits at the power limit, and
+  // what it needs is fewer instructions and bytes per MFMA, not a denser schedule.)
   f32x16 acc[TN][TM];
   auto four_steps = [&](const char* wq, auto&& mid) {
 #pragma unroll

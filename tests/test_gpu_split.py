@@ -74,7 +74,8 @@ def test_split_kernel_vs_c_oracle_and_fp32_kernel(name):
     if "s2" in name and "3x3" in name:     # strided 3x3: the patch holds every input pixel (4x the outputs); small tiles stay on the fp32 kernel
         if "fused_split_kernel" not in kn:
             pytest.skip("not eligible for the split flavour at this size: " + kn)
-    assert ("fused_split_kernel" in kn or "fused_split_direct_kernel" in kn) and "6 terms" in kn, kn     # (1x1 layers with K <= 256: the direct kernel)
+    # (1x1 layers with K <= 256: the direct kernel; narrow one-pixel heads: the split-K kernel)
+    assert ("fused_split_kernel" in kn or "fused_split_direct_kernel" in kn or "fused_split_skinny_kernel" in kn) and "6 terms" in kn, kn
     out32, kn32 = _run(mu, rho, mb, rb, x, conv, S, 1)
     assert "split" not in kn32, kn32
     dev = torch.device("cuda")
@@ -181,7 +182,7 @@ def test_linear_layers_on_the_split_kernel(In, Out, B, S, bias):
     c = lambda t: None if t is None else t.cuda()
     out, _ = F.fused_forward(c(x), c(mu), c(rho), c(mb), c(rb), S=S, seed=3, call=1, layer_id=4, sample0=2, packed=F.pack_params(c(mu), c(rho)))
     kn = _lib.lib().bt_last_kernel_name().decode()
-    assert "fused_split_kernel" in kn or "fused_split_direct_kernel" in kn, kn
+    assert "fused_split_kernel" in kn or "fused_split_direct_kernel" in kn or "fused_split_skinny_kernel" in kn, kn
     dev = torch.device("cuda")
     eps_w = F.rng_fill_normal(3, 1, 4, 2, 0, S, mu.shape, dev).cpu()
     eps_b = F.rng_fill_normal(3, 1, 4, 2, 1, S, (Out,), dev).cpu() if bias else None
