@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_fast_kernel(const FwdArg
       const double wsum = wave_sum(kl_acc);
       const int nslots = 4 * a.kl_slices;
       int last = 0;
-      if (lane == 0) last = publish_and_ticket(a.slots, a.counter, (int)blockIdx.x * 4 + wave, wsum, (unsigned)nslots) ? 1 : 0;
+      if (lane == 0) last = publish_and_ticket_wt(a.slots, a.counter, (int)blockIdx.x * 4 + wave, wsum, (unsigned)nslots) ? 1 : 0;
       if (__builtin_amdgcn_readfirstlane(last)) {  // this wave arrived last: every slot is published
         double t = 0.0;
         for (int q = lane; q < nslots; q += 64) t += __hip_atomic_load(&a.slots[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kKlThreads) void kl_normal_kernel(KlSegs sg, float*
     acc += (double)kl_term(mu[i], sig(rho[i]), pmu[i], psig[i]);
 
   const double bsum = block_sum_256(acc, red);
-  if (threadIdx.x == 0) is_last = publish_and_ticket(slots, counter, blockIdx.x, bsum, (unsigned)total_blocks) ? 1 : 0;
+  if (threadIdx.x == 0) is_last = publish_and_ticket_wt(slots, counter, blockIdx.x, bsum, (unsigned)total_blocks) ? 1 : 0;
   __syncthreads();
   if (!is_last) return;
   // last arriver: fixed-ORDER finish, in parallel. A segment's block partials are summed by the 256 threads in a fixed tree (thread t
