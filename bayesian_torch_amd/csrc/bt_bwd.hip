@@ -28,6 +28,9 @@ struct BwdArgs {
   const float *eps_w, *sign_in, *sign_out;  // injected draws (natural layouts) or null
   float *dx, *dmu, *drho;           // dx [S][B][Ci][H][W]; dmu / drho natural [Co][Cig][T]
   float *part;                      // wgrad partials [2][groups][Co][T][Cig4]
+  float *part_d;                    // dgrad partials [dchunks][S][x_elems] (behind wgrad's: the two passes may run in ONE launch)
+  int pair_wx, pair_wy, pair_nw, pair_dx, pair_dy;   // bwd_pair_kernel: wgrad's grid (x, y) and block count, dgrad's grid (x, y)
+  int fin_nw;                       // bwd_finish_pair_kernel: blocks of wgrad's finishing pass (the rest are dgrad's)
   long long x_sample_stride, x_elems, out_elems, w_elems;
   int B, Ci, H, W, Co, KH, KW, SH, SW, PH, PW, DH, DW, G;
   int Ho, Wo, Cig, Cog, Cig4, T, S, flip, groups;
@@ -56,15 +59,14 @@ __device__ __forceinline__ RngKey bwd_key(const BwdArgs& a, uint32_t tensor) {
 // position of the tile to an output are skipped (3x3 on 1x1 maps: 8 of 9). With dchunks > 1 a workgroup reduces over its
 // piece of the output channels and writes a partial; dgrad_finish_kernel adds the pieces in order.
 template <bool FLIP>
-__global__ __launch_bounds__(256) void dgrad_kernel(const BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[FLIP ? 2 : 1][kBK][kLS];   // [kk][ci]: W (Flipout: mu | sigma*eps)
-  __shared__ __attribute__((aligned(16))) float Bs[FLIP ? 2 : 1][kBK][kLS];   // [kk][col]: g (Flipout: g | g o s_out)
+__device__ __forceinline__ void dgrad_body(const BwdArgs& a, float (*As)[kBK][kLS], float (*Bs)[kBK][kLS], const int bx, const int by, const int bz) {
+  // As [kk][ci]: W (Flipout: mu | sigma*eps); Bs [kk][col]: g (Flipout: g | g o s_out)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-  const int kc = blockIdx.z / (a.S * a.G), zr = blockIdx.z - kc * (a.S * a.G);
+  const int kc = bz / (a.S * a.G), zr = bz - kc * (a.S * a.G);
   const int s = zr / a.G, grp = zr % a.G;
   const int co_lo = kc * a.dchunk, co_hi = co_lo + a.dchunk < a.Cog ? co_lo + a.dchunk : a.Cog;
-  const int ci0 = blockIdx.y * 64, m0 = blockIdx.x * 64;
+  const int ci0 = by * 64, m0 = bx * 64;
   const int HW = a.H * a.W, M = a.B * HW, HoWo = a.Ho * a.Wo;
   const uint32_t sample = a.sample0 + (uint32_t)s;
   const RngKey kw = bwd_key(a, 0);
@@ -145,34 +147,41 @@ __global__ __launch_bounds__(256) void dgrad_kernel(const BwdArgs a) {
         const long long xi = ((long long)b * a.Ci + grp * a.Cig + ci) * HW + hw;
         float v = acc[0][r];
         if (FLIP) v = __fadd_rn(v, __fmul_rn(acc[FLIP ? 1 : 0][r], a.sign_in ? a.sign_in[(long long)s * a.x_elems + xi] : hash_sign(skey_in, (uint32_t)xi)));
-        if (a.dchunks > 1) a.part[((long long)kc * a.S + s) * a.x_elems + xi] = v;
+        if (a.dchunks > 1) a.part_d[((long long)kc * a.S + s) * a.x_elems + xi] = v;
         else a.dx[(long long)s * a.x_elems + xi] = v;
       }
     }
   }
 }
 
-// dx <- sum of the dchunks partials, in piece order
-__global__ __launch_bounds__(256) void dgrad_finish_kernel(const BwdArgs a) {
+template <bool FLIP>
+__global__ __launch_bounds__(256) void dgrad_kernel(const BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[FLIP ? 2 : 1][kBK][kLS];
+  __shared__ __attribute__((aligned(16))) float Bs[FLIP ? 2 : 1][kBK][kLS];
+  dgrad_body<FLIP>(a, As, Bs, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// dx <- sum of the dchunks partials, in piece order (block bid of nb)
+__device__ __forceinline__ void dgrad_finish_body(const BwdArgs& a, const int bid, const int nb) {
   const long long n = (long long)a.S * a.x_elems;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+  for (long long i = (long long)bid * 256 + threadIdx.x; i < n; i += (long long)nb * 256) {
     float v = 0.f;
-    for (int c = 0; c < a.dchunks; ++c) v = __fadd_rn(v, a.part[(long long)c * n + i]);
+    for (int c = 0; c < a.dchunks; ++c) v = __fadd_rn(v, a.part_d[(long long)c * n + i]);
     a.dx[i] = v;
   }
 }
+__global__ __launch_bounds__(256) void dgrad_finish_kernel(const BwdArgs a) { dgrad_finish_body(a, blockIdx.x, gridDim.x); }
 
 // ------------------------------------------------------------------------------------------------------------ wgrad
 // grid: (k' tiles of 64 over T*Cig4) x (co tiles of 64 per group) x (groups * G); group q = (sample group q % sgroups: samples
 // s = q % sgroups + i * sgroups) x (chunk q / sgroups of the reduction axis M = B*Ho*Wo: rows [c * mchunk, (c + 1) * mchunk))
 template <bool FLIP>
-__global__ __launch_bounds__(256) void wgrad_kernel(const BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[FLIP ? 2 : 1][kBK][kLS];   // [mm][co]: g (Flipout: g | g o s_out)
-  __shared__ __attribute__((aligned(16))) float Bs[FLIP ? 2 : 1][kBK][kLS];   // [mm][k']: x window (Flipout: x | x o s_in)
+__device__ __forceinline__ void wgrad_body(const BwdArgs& a, float (*As)[kBK][kLS], float (*Bs)[kBK][kLS], const int bx, const int by, const int bz) {
+  // As [mm][co]: g (Flipout: g | g o s_out); Bs [mm][k']: x window (Flipout: x | x o s_in)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-  const int sgrp = blockIdx.z / a.G, grp = blockIdx.z % a.G;
-  const int co0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+  const int sgrp = bz / a.G, grp = bz % a.G;
+  const int co0 = by * 64, k0 = bx * 64;
   const int KP = a.T * a.Cig4, HW = a.H * a.W, HoWo = a.Ho * a.Wo, M = a.B * HoWo;
   const RngKey kw = bwd_key(a, 0);
   // this thread's staging columns: col = tid & 63 (a co for A, a k' for B), mm = (tid >> 6) + 4 j
@@ -266,6 +275,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const BwdArgs a) {
   }
 }
 
+template <bool FLIP>
+__global__ __launch_bounds__(256) void wgrad_kernel(const BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[FLIP ? 2 : 1][kBK][kLS];
+  __shared__ __attribute__((aligned(16))) float Bs[FLIP ? 2 : 1][kBK][kLS];
+  wgrad_body<FLIP>(a, As, Bs, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Both passes of a layer in ONE launch: they read the same upstream gradient and are independent of each other, and at one sample per
+// step each is a few hundred short workgroups -- 28 + 35 us back to back on ResNet18 / CIFAR, the longer of the two side by side.
+// Blocks [0, pair_nw) are wgrad's grid (x fastest, then y, then z) -- the longer pass first --, the rest dgrad's.
+template <bool FLIP>
+__global__ __launch_bounds__(256) void bwd_pair_kernel(const BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[FLIP ? 2 : 1][kBK][kLS];
+  __shared__ __attribute__((aligned(16))) float Bs[FLIP ? 2 : 1][kBK][kLS];
+  int L = blockIdx.x;
+  if (L < a.pair_nw) {
+    const int q = L / a.pair_wx, bx = L - q * a.pair_wx, bz = q / a.pair_wy, by = q - bz * a.pair_wy;
+    wgrad_body<FLIP>(a, As, Bs, bx, by, bz);
+  } else {
+    L -= a.pair_nw;
+    const int q = L / a.pair_dx, bx = L - q * a.pair_dx, bz = q / a.pair_dy, by = q - bz * a.pair_dy;
+    dgrad_body<FLIP>(a, As, Bs, bx, by, bz);
+  }
+}
+
 // (dKL/dmu, dKL/drho) of ONE element of kl_div's mean (base_variational_layer.py:70-72; 'laplace': :74-97), times gs = upstream / n.
 // The op order of kl_normal_bwd_kernel below (which calls it): a gradient built here and one built there are the same bits.
 __device__ __forceinline__ void kl_elem_grad(float m, float r, const float* pmu, const float* psig, long long i, int laplace, float gs, float& dm, float& dr) {
@@ -287,12 +321,12 @@ __device__ __forceinline__ void kl_elem_grad(float m, float r, const float* pmu,
 
 // natural element (co, ci, tap) <- sum over the groups' partials at the tap-major position, in group order; with a.gkl also the
 // layer's KL term: grad = (contraction path) + (KL path), the sum autograd's AccumulateGrad would have made of the two tensors.
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(const BwdArgs a) {
+__device__ __forceinline__ void wgrad_finish_body(const BwdArgs& a, const int bid, const int nb) {
   const long long n = (long long)a.Co * a.Cig * a.T;
   const int KP = a.T * a.Cig4;
   const long long plane = (long long)a.Co * KP;
   const float gkl_s = a.gkl ? a.gkl[0] / (float)n : 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+  for (long long i = (long long)bid * 256 + threadIdx.x; i < n; i += (long long)nb * 256) {
     const int tap = (int)(i % a.T);
     const long long rc = i / a.T;
     const int ci = (int)(rc % a.Cig), co = (int)(rc / a.Cig);
@@ -310,6 +344,11 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const BwdArgs a) {
     if (a.dmu) a.dmu[i] = om;
     if (a.drho) a.drho[i] = orr;
   }
+}
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const BwdArgs a) { wgrad_finish_body(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void bwd_finish_pair_kernel(const BwdArgs a) {   // blocks [0, fin_nw): wgrad's finishing pass, the rest dgrad's
+  if ((int)blockIdx.x < a.fin_nw) wgrad_finish_body(a, blockIdx.x, a.fin_nw);
+  else dgrad_finish_body(a, (int)blockIdx.x - a.fin_nw, (int)gridDim.x - a.fin_nw);
 }
 
 // dKL/dmu, dKL/drho of the normal-prior KL (base_variational_layer.py:70-72), scaled by the upstream gradient g[0] / n
@@ -407,8 +446,8 @@ extern "C" size_t bt_conv2d_bwd_workspace(const bt_conv2d_geom* g, int32_t S) {
   const int Cig = g->Ci / g->groups, Cig4 = (Cig + 3) & ~3, T = g->kh * g->kw;
   const size_t wg = (size_t)2 * bt::wgrad_groups(*g, S) * g->Co * T * Cig4 * sizeof(float);
   const int dc = bt::dgrad_chunks(*g, S);
-  const size_t dg = dc > 1 ? (size_t)dc * S * g->B * g->Ci * g->H * g->W * sizeof(float) : 0;   // (the two passes run one after the other)
-  return wg > dg ? wg : dg;
+  const size_t dg = dc > 1 ? (size_t)dc * S * g->B * g->Ci * g->H * g->W * sizeof(float) : 0;
+  return wg + dg;   // (wgrad's partials, then dgrad's: the two passes run side by side in one launch when both are asked for)
 }
 
 static int conv2d_bwd_impl(const bt_conv2d_geom* g, int32_t S, int32_t flipout, const float* x, int64_t x_sample_stride, const float* grad_out,
@@ -445,30 +484,49 @@ static int conv2d_bwd_impl(const bt_conv2d_geom* g, int32_t S, int32_t flipout, 
   a.seed_lo = (uint32_t)d->rng.seed, a.seed_hi = (uint32_t)(d->rng.seed >> 32);
   a.call = d->rng.call, a.call_base = d->rng.call_base_dev, a.layer_id = d->rng.layer_id, a.sample0 = d->rng.sample0;
   hipStream_t st = (hipStream_t)stream;
+  const size_t need_ws = bt_conv2d_bwd_workspace(g, S);
+  dim3 dgrid(1, 1, 1), wgrid(1, 1, 1);
+  long long n_dfin = 0, n_wfin = 0;
   if (dx) {
     const long long M = (long long)g->B * g->H * g->W;
     a.dchunks = dgrad_chunks(*g, S, &a.dchunk);
-    if (a.dchunks > 1 && (!workspace || workspace_bytes < bt_conv2d_bwd_workspace(g, S)))
+    if (a.dchunks > 1 && (!workspace || workspace_bytes < need_ws))
       return set_error(BT_ERR_WORKSPACE, "bt_conv2d_bwd: workspace smaller than bt_conv2d_bwd_workspace()");
-    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((a.Cig + 63) / 64), (unsigned)(S * g->groups * a.dchunks));
-    if (flipout) hipLaunchKernelGGL(dgrad_kernel<true>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(dgrad_kernel<false>, grid, dim3(256), 0, st, a);
+    dgrid = dim3((unsigned)((M + 63) / 64), (unsigned)((a.Cig + 63) / 64), (unsigned)(S * g->groups * a.dchunks));
+    if (a.dchunks > 1) n_dfin = ((long long)S * a.x_elems + 255) / 256 > 4096 ? 4096 : ((long long)S * a.x_elems + 255) / 256;
+  }
+  if (dmu_w) {
+    a.groups = wgrad_groups(*g, S, &a.sgroups, &a.mchunk);
+    if (!workspace || workspace_bytes < need_ws) return set_error(BT_ERR_WORKSPACE, "bt_conv2d_bwd: workspace smaller than bt_conv2d_bwd_workspace()");
+    wgrid = dim3((unsigned)((a.T * a.Cig4 + 63) / 64), (unsigned)((a.Cog + 63) / 64), (unsigned)(a.groups * g->groups));
+    n_wfin = (a.w_elems + 255) / 256 > 4096 ? 4096 : (a.w_elems + 255) / 256;
+  }
+  // dgrad's partials live behind wgrad's
+  a.part_d = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (size_t)2 * wgrad_groups(*g, S) * g->Co * a.T * a.Cig4 * sizeof(float));
+  const long long nwb = (long long)wgrid.x * wgrid.y * wgrid.z, ndb = (long long)dgrid.x * dgrid.y * dgrid.z;
+  if (dx && dmu_w && nwb + ndb < 0x7FFFFFFFll) {   // both passes: ONE launch, and one for the two finishing passes
+    a.pair_wx = (int)wgrid.x, a.pair_wy = (int)wgrid.y, a.pair_nw = (int)nwb, a.pair_dx = (int)dgrid.x, a.pair_dy = (int)dgrid.y;
+    if (flipout) hipLaunchKernelGGL(bwd_pair_kernel<true>, dim3((unsigned)(nwb + ndb)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(bwd_pair_kernel<false>, dim3((unsigned)(nwb + ndb)), dim3(256), 0, st, a);
+    if (int rc = check_launch("bt_conv2d_bwd (wgrad + dgrad)")) return rc;
+    a.fin_nw = (int)n_wfin;
+    hipLaunchKernelGGL(bwd_finish_pair_kernel, dim3((unsigned)(n_wfin + n_dfin)), dim3(256), 0, st, a);
+    return check_launch("bt_conv2d_bwd (finish)");
+  }
+  if (dx) {
+    if (flipout) hipLaunchKernelGGL(dgrad_kernel<true>, dgrid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dgrad_kernel<false>, dgrid, dim3(256), 0, st, a);
     if (int rc = check_launch("bt_conv2d_bwd (dgrad)")) return rc;
     if (a.dchunks > 1) {
-      const long long n = (long long)S * a.x_elems;
-      hipLaunchKernelGGL(dgrad_finish_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(dgrad_finish_kernel, dim3((unsigned)n_dfin), dim3(256), 0, st, a);
       if (int rc = check_launch("bt_conv2d_bwd (dgrad finish)")) return rc;
     }
   }
   if (dmu_w) {
-    a.groups = wgrad_groups(*g, S, &a.sgroups, &a.mchunk);
-    if (!workspace || workspace_bytes < bt_conv2d_bwd_workspace(g, S)) return set_error(BT_ERR_WORKSPACE, "bt_conv2d_bwd: workspace smaller than bt_conv2d_bwd_workspace()");
-    dim3 grid((unsigned)((a.T * a.Cig4 + 63) / 64), (unsigned)((a.Cog + 63) / 64), (unsigned)(a.groups * g->groups));
-    if (flipout) hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(256), 0, st, a);
+    if (flipout) hipLaunchKernelGGL(wgrad_kernel<true>, wgrid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_kernel<false>, wgrid, dim3(256), 0, st, a);
     if (int rc = check_launch("bt_conv2d_bwd (wgrad)")) return rc;
-    const long long n = a.w_elems;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)n_wfin), dim3(256), 0, st, a);
     if (int rc = check_launch("bt_conv2d_bwd (finish)")) return rc;
   }
   return BT_OK;
