@@ -548,7 +548,7 @@ def train_bench(args, w, dev, world, rank):
                               value=round(world * args.steps / dt, 2), unit="MC-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                               ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
                               data="synthetic", config=dict(workload=w["desc"], batch=B, mc_samples_per_step=1, optimizer="SGD momentum 0.9",
-                                                            backward="HIP dgrad/wgrad kernels, draws regenerated on chip",
+                                                            backward="HIP dgrad + wgrad kernels (one launch per layer), draws regenerated on chip; the KL term's gradient is taken inside the weight-gradient pass (bt_conv2d_bwd_kl), its value by one bt_kl_normal launch per model",
                                                             launch="eager" if args.no_graph else "hip graph replay (mc.TrainGraph)"))))
     if world > 1:
         dist.destroy_process_group()

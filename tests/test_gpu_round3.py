@@ -501,3 +501,33 @@ def test_kl_term_differentiated_inside_wgrad_equals_autograd_sum(case):
         assert_close(gx1, gx2, 2e-4, 2e-5, case + ".dx vs aten")
         for (n, _), a, b in zip(layer.named_parameters(), g1, g2):
             assert_close(a, b, 2e-4, 2e-5, f"{case}: grad of {n} vs aten")
+
+
+def test_bwd_kl_entry_point_rejects_incomplete_arguments():
+    """bt_conv2d_bwd_kl: grad_kl without the weight-gradient outputs, or without mu_w / the priors, is a BT_ERR_BAD_ARG, not a launch."""
+    import ctypes as C
+    from bayesian_torch_amd import _lib
+    from bayesian_torch_amd import functional as F
+    dev = torch.device("cuda")
+    L = _lib.lib()
+    mu, rho = torch.randn(8, 8, 1, 1, device=dev), torch.randn(8, 8, 1, 1, device=dev) - 3
+    pk = F.pack_params(mu, rho)
+    x, g, gkl = torch.randn(4, 8, 2, 2, device=dev), torch.randn(4, 8, 2, 2, device=dev), torch.ones(1, device=dev)
+    geom = _lib.bt_conv2d_geom(4, 8, 2, 2, 8, 1, 1, 1, 1, 0, 0, 1, 1, 1)
+    ws = torch.empty(max(16, L.bt_conv2d_bwd_workspace(C.byref(geom), 1)), dtype=torch.uint8, device=dev)
+    dx, dmu, drho = torch.empty_like(x), torch.empty_like(mu), torch.empty_like(mu)
+    D = _lib.bt_draws(None, None, None, None, F._rng(1, 0, 0, 0, None))
+
+    def call(P, dmu_, drho_):
+        return L.bt_conv2d_bwd_kl(C.byref(geom), 1, 0, x.data_ptr(), 0, g.data_ptr(), C.byref(P), C.byref(D), gkl.data_ptr(), dx.data_ptr(), _lib.ptr(dmu_), _lib.ptr(drho_),
+                                  ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
+    no_priors = _lib.bt_params(mu.data_ptr(), rho.data_ptr(), None, None, None, None, None, None, pk[0].data_ptr(), pk[1].data_ptr(), 0, 0)
+    assert call(no_priors, dmu, drho) < 0 and b"priors" in L.bt_last_error_string()
+    pm, ps = torch.zeros_like(mu), torch.ones_like(mu)
+    full = _lib.bt_params(mu.data_ptr(), rho.data_ptr(), None, None, pm.data_ptr(), ps.data_ptr(), None, None, pk[0].data_ptr(), pk[1].data_ptr(), 0, 0)
+    assert call(full, None, None) < 0 and b"grad_kl needs" in L.bt_last_error_string()
+    assert call(full, dmu, drho) == 0
+    lap = _lib.bt_params(mu.data_ptr(), rho.data_ptr(), None, None, None, None, None, None, pk[0].data_ptr(), pk[1].data_ptr(), 1, 0)
+    assert call(lap, dmu, drho) == 0      # the Laplace branch reads no prior tensors (base_variational_layer.py:74-97)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dmu).all() and torch.isfinite(drho).all()

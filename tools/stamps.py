@@ -9,7 +9,7 @@ sys.argv = [sys.argv[0]] + sys.argv[1:]
 import argparse
 ap = argparse.ArgumentParser(); ap.add_argument("--shape", default="layer1"); ap.add_argument("--S", type=int, default=32); ap.add_argument("--B", type=int, default=128); ap.add_argument("--sigma", action="store_true"); ap.add_argument("--noprio", action="store_true"); ap.add_argument("--prio", type=int, default=0); ap.add_argument("--wgs", action="store_true", help="per-workgroup timeline"); ap.add_argument("--pool", action="store_true")
 a = ap.parse_args()
-SH = {"conv1": (3, 64, 7, 2, 3, 32), "layer1": (64, 64, 3, 1, 1, 8), "layer2": (128, 128, 3, 1, 1, 4), "layer3": (256, 256, 3, 1, 1, 2), "layer4": (512, 512, 3, 1, 1, 1), "ds2": (64, 128, 1, 2, 0, 8), "l2s": (64, 128, 3, 2, 1, 8), "ds4": (256, 512, 1, 2, 0, 2)}
+SH = {"conv1": (3, 64, 7, 2, 3, 32), "r50conv1": (3, 64, 7, 2, 3, 224), "layer1": (64, 64, 3, 1, 1, 8), "layer2": (128, 128, 3, 1, 1, 4), "layer3": (256, 256, 3, 1, 1, 2), "layer4": (512, 512, 3, 1, 1, 1), "ds2": (64, 128, 1, 2, 0, 8), "l2s": (64, 128, 3, 2, 1, 8), "ds4": (256, 512, 1, 2, 0, 2)}
 pri = None
 Ci, Co, k, st, pd, H = SH[a.shape]
 dev = torch.device("cuda")
