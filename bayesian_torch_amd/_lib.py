@@ -64,6 +64,7 @@ _PROTOS = {
     "bt_conv2d_bwd_workspace": (C.c_size_t, [C.POINTER(bt_conv2d_geom), C.c_int32]),
     "bt_conv2d_bwd": (C.c_int, [C.POINTER(bt_conv2d_geom), C.c_int32, C.c_int32, _vp, C.c_int64, _vp, C.POINTER(bt_params), C.POINTER(bt_draws),
                                 _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "bt_maxpool_3x3s2": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_int32, _vp]),
     "bt_conv2d_bwd_kl": (C.c_int, [C.POINTER(bt_conv2d_geom), C.c_int32, C.c_int32, _vp, C.c_int64, _vp, C.POINTER(bt_params), C.POINTER(bt_draws), _vp,
                                    _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "bt_kl_normal_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_uint32, _vp, _vp, _vp]),

@@ -19,8 +19,18 @@ def fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, pool=False, **kw):
     r = _fused_forward(x, mu_w, rho_w, mu_b, rho_b, pool=True, **kw)
     if r is None:  # BT_ERR_UNSUPPORTED: nothing was launched
         out, kl = _fused_forward(x, mu_w, rho_w, mu_b, rho_b, pool=False, **kw)
-        return torch.nn.functional.max_pool2d(out, 3, 2, 1), kl
+        return maxpool_3x3s2(out), kl
     return r
+
+
+def maxpool_3x3s2(x):
+    """MaxPool2d(3, 2, 1) of an NCHW tensor on the HIP pooling pass (bt_maxpool_3x3s2): the same bits as torch's max_pool2d."""
+    x = _lib.dev_f32(x, "input")
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    with _lib.on(x.device):
+        _lib.check(_lib.lib().bt_maxpool_3x3s2(x.data_ptr(), out.data_ptr(), N * Cc, H, W, _lib.stream_ptr(x.device)))
+    return out
 
 
 def _fused_forward(x, mu_w, rho_w, mu_b=None, rho_b=None, *, flip=False, conv=None, S=1, shared_x=True,

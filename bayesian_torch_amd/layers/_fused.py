@@ -264,6 +264,7 @@ class FusedBayesLayer(BaseVariationalLayer_):
                 opts["kl_stub"] = not want_kl       # nobody reads this layer's KL by itself: one launch per model computes the value
                 out, kl = FusedForward.apply(x, mu_t, rho_t, self.mu_bias, self.rho_bias, opts)
                 self._kl_live = (kl, self._param_versions(), opts["kl_stub"])
+                ctx.live_layers.append(self)     # (TrainGraph drops whatever the loss did not pick up: the tensor holds this forward's graph)
             else:
                 out = FusedForward.apply(x, mu_t, rho_t, self.mu_bias, self.rho_bias, opts)
                 kl = None

@@ -27,6 +27,7 @@ class McContext:
         self.pack_event = None   # recorded on the side stream that verifies every layer but the first (sync_model_packs)
         self.late = set()        # id() of the layers verified there: the first of them to run makes the launch stream wait
         self.train_fused = False  # TrainGraph: forwards carry their KL term along (FusedForward's second output) ...
+        self.live_layers = []    # layers holding a live KL tensor of this context (layers/_fused.py: _kl_live)
         self.deferred = None     # ... and (a list) hand their weight gradients over here, computed on the side stream: (layer, dmu, drho, device)
 
 
@@ -228,6 +229,8 @@ class TrainGraph:
             loss = loss_fn(model, out, self.y)
             loss.backward()
             finish_deferred(ctx)
+            for layer in ctx.live_layers:      # a loss that never asked for the KL leaves the tensors (and their graph) behind
+                layer._kl_live = None
             optimizer.step()
             return loss.detach()
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BT_VERSION 301
+#define BT_VERSION 302
 #define BT_WORKSPACE_BYTES 65536
 
 #define BT_OK 0
@@ -269,6 +269,11 @@ int bt_set_contraction(int mode);
 /* MC epilogue (examples/main_bayesian_cifar_dnn2bnn.py:551-557 and :402-412): from logits [S][B][C]
  * accumulate into packed[B*C + B + B*C] = [sum_s softmax | sum_s entropy | sum_s logits] (overwrites). */
 int bt_mc_epilogue(int32_t S, int32_t B, int32_t C, const float *logits, float *packed, bt_stream_t stream);
+/* MaxPool2d(kernel 3, stride 2, padding 1) over `planes` contiguous H x W planes (NCHW with planes = N * C): out holds planes x
+ * ((H-1)/2+1) x ((W-1)/2+1). The pooling pass behind a stem whose fused launch returned BT_ERR_UNSUPPORTED for bt_epilogue.pool
+ * (its tiles do not hold whole output images: the 112 x 112 ImageNet stem) -- `nn.MaxPool2d(3, 2, 1)` of the example models
+ * (models/deterministic/resnet_large.py:120). Same comparisons as torch's max_pool2d (NaNs propagate): the same bits. */
+int bt_maxpool_3x3s2(const float *in, float *out, int64_t planes, int32_t H, int32_t W, bt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -531,3 +531,22 @@ def test_bwd_kl_entry_point_rejects_incomplete_arguments():
     assert call(lap, dmu, drho) == 0      # the Laplace branch reads no prior tensors (base_variational_layer.py:74-97)
     torch.cuda.synchronize()
     assert torch.isfinite(dmu).all() and torch.isfinite(drho).all()
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 112, 112), (2, 3, 7, 9), (1, 1, 1, 1), (2, 2, 16, 130), (1, 4, 33, 2), (1, 2, 5, 300)])
+def test_hip_maxpool_pass_equals_torch(shape):
+    """bt_maxpool_3x3s2 (the stem's pooling when it cannot be fused: row-band tiles) against torch's max_pool2d(3, 2, 1): bit for bit,
+    odd and even widths, rows longer than a wave, -inf and NaN inputs."""
+    from bayesian_torch_amd import functional as F
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).cuda()
+    if x.numel() > 20:
+        x.view(-1)[7] = float("nan")
+        x.view(-1)[11] = float("-inf")
+    want = torch.nn.functional.max_pool2d(x, 3, 2, 1)
+    got = F.maxpool_3x3s2(x)
+    assert got.shape == want.shape
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    assert torch.equal(torch.nan_to_num(got, nan=0.0), torch.nan_to_num(want, nan=0.0))
+    xv = x[:, :, 1:, :][:, :, :, 1:] if min(shape[2:]) > 2 else x      # a view whose planes are not 8-byte aligned goes through dev_f32's copy
+    assert torch.equal(torch.nan_to_num(F.maxpool_3x3s2(xv), nan=0.0), torch.nan_to_num(torch.nn.functional.max_pool2d(xv, 3, 2, 1), nan=0.0))
