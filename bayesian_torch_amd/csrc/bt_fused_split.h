@@ -364,7 +364,11 @@ __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdAr
 
   const int prio_mode = dbg_ ? (int)dbg_[200] : 0;  // diagnostic build: 0 producers first (product), 1 none, 2 consumers first
   if (producer) {
-    if (prio_mode == 0) __builtin_amdgcn_s_setprio(3);
+    // Producers first on the 512-wide tiles (layer1: 131.5 us against 139.0 without, tools/stamps.py --noprio) and in the Flipout flavour;
+    // NOT on the narrower Reparameterization tiles, whose consumer stage is the longer one (profiles/r03_stamps_layer3.txt): same-box
+    // A/B inside the cfg3 graph (tools/trace_layers.py, BT_LIB_PATH): the strided 3x3 layers 88.2 -> 84.8, 82.2 -> 79.1, 72.3 -> 66.5 us,
+    // layer4's one-tap layers -2 us each, the 512-wide launches unchanged: 1928.7 -> 1909.1 us per step.
+    if (prio_mode == 0 && (BM == 512 || FLIP)) __builtin_amdgcn_s_setprio(3);
     // =================================================== PRODUCERS ===========================================================
     // Weight unit u = (channel quad cq of the octet, row n, entry q = (octet ol, tap slot ai)): 4 sampled weights = one Philox
     // block. u = ptid + 256 i -> cq = u & 1, n = (u >> 1) % BN, q = (u >> 1) / BN: consecutive lanes fill one 16-byte LDS slot
