@@ -146,7 +146,15 @@ static int launch_direct(FwdArgs& a, hipStream_t stream) {
   const int nsub = (a.M + 63) / 64;
   // chunks of the pixel range per (group, channel tile, sample): ~1024 workgroups in all (four per CU: the tail of an uneven split
   // is a quarter of a workgroup's work), each with at least 64 sub-tiles (8 per wave) to walk
-  long long chunks = (1024 + pairs - 1) / pairs;
+  // Measured at ResNet50 / b256 / S = 16 (tools/ab_direct_wgs.sh, env BT_DIRECT_WGS): the STREAMED flavour re-draws its weight chunks per
+  // 512 pixels whatever the split, so extra workgroups only add prologues and KL slices -- one per CU is best (K = 2048 -> 512 on 7x7:
+  // 3260 -> 2805 us; K = 1024 -> 256 on 14x14: 3065 -> 2947); a STRIDED resident layer (the downsamples: half of every fetched line
+  // is unused) likes short workgroups that spread its fetches (256 -> 512 stride 2 on 56x56: 8001 -> 7253 us at 4096); everything else
+  // stays at four per CU.
+  static const int wg_env = [] { const char* e = getenv("BT_DIRECT_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();   // measurement knob
+  static const int n_cu = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
+  const int wg_target = wg_env ? wg_env : !resident ? n_cu : (a.SH > 1 || a.SW > 1) ? 16 * n_cu : 4 * n_cu;
+  long long chunks = (wg_target + pairs - 1) / pairs;
   if (chunks > nsub / 64) chunks = nsub / 64;
   if (chunks < 1) {   // few pixels (CIFAR-sized maps): down to one sub-tile per wave, as long as that still adds workgroups the chip has room for
     chunks = (256 + pairs - 1) / pairs;
@@ -288,7 +296,11 @@ static int launch_split_one(FwdArgs& a, hipStream_t stream) {
   };
   const double c512 = cost(live512, 512, b512), c256 = cost(live256, 256, b256), c128 = cost(live128, 128, b128);
   int bm = 0;
-  if (c512 < 1e30 && c512 <= c256 && c512 <= c128) bm = 512;
+  static const int force_bm = [] { const char* e = getenv("BT_FORCE_BM"); return e ? atoi(e) : 0; }();   // measurement knob: prefer this tile width where it is eligible
+  if (force_bm == 512 && c512 < 1e30) bm = 512;
+  else if (force_bm == 256 && c256 < 1e30) bm = 256;
+  else if (force_bm == 128 && c128 < 1e30) bm = 128;
+  else if (c512 < 1e30 && c512 <= c256 && c512 <= c128) bm = 512;
   else if (c256 < 1e30 && c256 <= c128) bm = 256;
   else if (c128 < 1e30) bm = 128;
   if (!bm) return 1;

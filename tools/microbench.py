@@ -10,6 +10,8 @@ from bayesian_torch_amd import functional as F
 SHAPES = {  # Ci, Co, k, stride, pad, H
     "conv1": (3, 64, 7, 2, 3, 32), "layer1": (64, 64, 3, 1, 1, 8), "layer2": (128, 128, 3, 1, 1, 4), "layer2s": (64, 128, 3, 2, 1, 8),
     "r50l3c3": (256, 1024, 1, 1, 0, 14), "r50l3c1": (1024, 256, 1, 1, 0, 14), "r50l1c3": (64, 256, 1, 1, 0, 56), "r50l2ds": (256, 512, 1, 2, 0, 56),
+    "r50l3ds": (512, 1024, 1, 2, 0, 28), "r50l4ds": (1024, 2048, 1, 2, 0, 14), "r50l4c1": (2048, 512, 1, 1, 0, 7), "r50l4c3": (512, 2048, 1, 1, 0, 7),
+    "r50l2c1": (512, 128, 1, 1, 0, 28), "r50l2c3": (128, 512, 1, 1, 0, 28), "r50l1ds": (64, 256, 1, 1, 0, 56),
     "layer3": (256, 256, 3, 1, 1, 2), "layer4": (512, 512, 3, 1, 1, 1), "ds4": (256, 512, 1, 2, 0, 2), "l4s": (256, 512, 3, 2, 1, 2),
 }
 ap = argparse.ArgumentParser()
