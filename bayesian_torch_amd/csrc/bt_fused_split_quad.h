@@ -304,9 +304,8 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
   }
   if (stamp0) dbg_[212] = __builtin_amdgcn_s_memtime();   // patch staged (this thread's share)
   if (producer) {
-    // (producers first only in the Flipout flavour: without the priority the Reparameterization stem measured 228 -> 222 us alone and
-    //  253.5 -> 247.7 us inside the cfg3 graph, same box, BT_LIB_PATH A/B)
-    if constexpr (FLIP) __builtin_amdgcn_s_setprio(3);
+    // (no producer priority here, unlike bt_fused_split.h's wide tiles: without it the Reparameterization stem measured 228 -> 222 us alone
+    //  and 253.5 -> 247.7 us inside the cfg3 graph, the Flipout stem 474.0 -> 459.1 us inside cfg4's -- same box, BT_LIB_PATH A/B)
     // =================================================== PRODUCERS ===========================================================
     // ---- weights: unit u = (row n = u & 63, tap slot of the stage q = u >> 6): 4 sampled weights = one Philox block ----
     constexpr int UMAX = (BN * TPS + kProducers - 1) / kProducers;  // 5
@@ -387,7 +386,6 @@ __global__ __launch_bounds__(512) void fused_split_quad_kernel(const FwdArgs a) 
       osh[ptid] = cv ? sh : 0.f;
     }
     __syncthreads();
-    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     if constexpr (FLIP) {
       combine_flip(tid);
