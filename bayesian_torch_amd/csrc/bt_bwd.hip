@@ -405,7 +405,10 @@ __global__ __launch_bounds__(256) void kl_normal_bwd_segs_kernel(const KlBwdSegs
 static int wgrad_groups(const bt_conv2d_geom& g, int S, int* sgroups = nullptr, int* mchunk = nullptr) {
   const int Cig = g.Ci / g.groups, Cog = g.Co / g.groups, Cig4 = (Cig + 3) & ~3, T = g.kh * g.kw;
   const long long tiles = (long long)((T * Cig4 + 63) / 64) * ((Cog + 63) / 64) * g.groups;
-  long long gr = (512 + tiles - 1) / tiles;  // aim at two workgroups per CU
+  static const int w_target = [] { const char* e = getenv("BT_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();   // measurement knob
+  // One workgroup per CU: the pass runs beside dgrad in one launch (bwd_pair_kernel) and every group costs a partial that the finishing
+  // pass reads back (ResNet18 step, env sweep: 512 -> 3.14 ms, 256 -> 2.97, 192 -> 2.98, 128 -> 3.24, 1024 -> 3.22).
+  long long gr = (w_target + tiles - 1) / tiles;
   if (gr < 1) gr = 1;
   const long long gs = gr > S ? S : gr;
   const int Ho = (g.H + 2 * g.ph - g.dh * (g.kh - 1) - 1) / g.sh + 1, Wo = (g.W + 2 * g.pw - g.dw * (g.kw - 1) - 1) / g.sw + 1;
@@ -428,7 +431,8 @@ static int dgrad_chunks(const bt_conv2d_geom& g, int S, int* dchunk = nullptr) {
   const int Cig = g.Ci / g.groups, Cog = g.Co / g.groups;
   const long long M = (long long)g.B * g.H * g.W;
   const long long tiles = ((M + 63) / 64) * ((Cig + 63) / 64) * S * g.groups;
-  long long c = (512 + tiles - 1) / tiles;
+  static const int d_target = [] { const char* e = getenv("BT_DGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();   // measurement knob
+  long long c = (d_target + tiles - 1) / tiles;
   const long long max_c = (Cog + 31) / 32;
   if (c > max_c) c = max_c;
   if (c < 1) c = 1;
