@@ -141,6 +141,9 @@ def dev_f32(t, what):
 
 def stream_ptr(device=None):
     """The current torch stream OF ``device`` (not of whatever device happens to be current)."""
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)     # the handle without a Stream object (the eager path asks twice per layer)
+    if raw is not None and isinstance(device, torch.device) and device.index is not None:
+        return raw(device.index)
     return torch.cuda.current_stream(device).cuda_stream
 
 

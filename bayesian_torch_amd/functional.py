@@ -190,6 +190,12 @@ def pack_sync(segments, owner="pack"):
         return
     L = _lib.lib()
     dev = segments[0]["mu"].device
+    if len(segments) == 1 and "_c" in segments[0]:      # a layer checking itself again: its marshalled entry is still valid (same tensors, same buffers)
+        arr = segments[0]["_c"][0]
+        arr[0].force = 1 if segments[0].get("force") else 0
+        with _lib.on(dev):
+            _lib.check(L.bt_pack_sync(1, arr, _lib.workspace((owner, "pack"), dev).data_ptr(), _lib.WORKSPACE_BYTES, _lib.stream_ptr(dev)))
+        return
     for c0 in range(0, len(segments), _lib.PACK_MAX_SEGMENTS):
         chunk = segments[c0:c0 + _lib.PACK_MAX_SEGMENTS]
         arr = (_lib.bt_pack_seg * len(chunk))()
@@ -206,6 +212,8 @@ def pack_sync(segments, owner="pack"):
                 raise RuntimeError("pack_sync: geometry does not match the parameter tensors")
             arr[i] = _lib.bt_pack_seg(mu.data_ptr(), rho.data_ptr(), _lib.ptr(smu), _lib.ptr(srho), sg["mu_packed"].data_ptr(), sg["sigma_packed"].data_ptr(),
                                       sg["state"].data_ptr(), sg["Co"], sg["Ci"], sg["taps"], 1 if sg.get("force") else 0, 0)
+        if len(segments) == 1:
+            segments[0]["_c"] = (arr, keep)
         with _lib.on(dev):
             _lib.check(L.bt_pack_sync(len(chunk), arr, _lib.workspace((owner, "pack"), dev).data_ptr(), _lib.WORKSPACE_BYTES, _lib.stream_ptr(dev)))
 

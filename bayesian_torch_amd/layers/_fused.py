@@ -22,6 +22,10 @@ from .base_variational_layer import BaseVariationalLayer_, check_prior_type, get
 _warned = [False]
 
 
+import os as _os
+_NO_SEG_CACHE = bool(_os.environ.get("BT_NO_SEG_CACHE"))   # A/B knob of the eager path's host time (tools/profile_eager.py)
+
+
 class FusedBayesLayer(BaseVariationalLayer_):
     _kind = "linear"     # or "conv"
     _flip = False
@@ -144,7 +148,17 @@ class FusedBayesLayer(BaseVariationalLayer_):
         """This layer's entry of a bt_pack_sync call. The pack lives in persistent buffers (a captured graph bakes their
         addresses in; they are re-allocated -- and rebuilt unconditionally -- only when a parameter TENSOR is replaced:
         ``.to(device)``, a new nn.Parameter)."""
-        mu, rho = self._w("mu").detach(), self._w("rho").detach()
+        pm, pr = self._w("mu"), self._w("rho")
+        cached = getattr(self, "_seg_cache", None)
+        if (not _NO_SEG_CACHE and cached is not None and self._pack is not None and cached[0] is self._pack and cached[1] == (pm.data_ptr(), pr.data_ptr(), pm.device)
+                and type(self)._pack_source is FusedBayesLayer._pack_source):
+            # same parameter tensors, same persistent buffers: the entry of the last call (a layer called on its own builds one per
+            # forward -- 21 per model forward in the reference's eager loop, which is host-bound)
+            sg = cached[2]
+            sg["force"] = self._pack_force
+            self._pack_force = False
+            return sg
+        mu, rho = pm.detach(), pr.detach()
         smu, srho = self._pack_source()
         Co, Ci = smu.shape[0], smu.shape[1]
         taps = 1
@@ -157,8 +171,10 @@ class FusedBayesLayer(BaseVariationalLayer_):
             force = True
         self._pack_force = False
         same = smu.data_ptr() == mu.data_ptr() and srho.data_ptr() == rho.data_ptr()
-        return dict(mu=mu, rho=rho, src_mu=None if same else smu.contiguous(), src_rho=None if same else srho.contiguous(), mu_packed=self._pack[1],
-                    sigma_packed=self._pack[2], state=self._pack[3], Co=Co, Ci=Ci, taps=taps, force=force)
+        sg = dict(mu=mu, rho=rho, src_mu=None if same else smu.contiguous(), src_rho=None if same else srho.contiguous(), mu_packed=self._pack[1],
+                  sigma_packed=self._pack[2], state=self._pack[3], Co=Co, Ci=Ci, taps=taps, force=force)
+        self._seg_cache = (self._pack, (pm.data_ptr(), pr.data_ptr(), pm.device), sg) if same else None
+        return sg
 
     def _packed(self):
         """(mu_packed, sigma_packed): tap-major copies of (mu, softplus(rho)) for the fast kernels, verified against the
