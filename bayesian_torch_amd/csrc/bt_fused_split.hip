@@ -213,7 +213,8 @@ static bool skinny_plan(int B, int Ci, int H, int W, int Co, int KH, int KW, int
   // kernel; layer4's 3x3 layers with one live tap (32 per sample) 53 ... 60 -> 60; layer4.0.conv1 with four live taps (64 per sample,
   // 2048 workgroups) 71 -> 140: past a few slices per sample the slabs' HBM round trip (2 x 32 KB per workgroup) and the second round
   // of workgroups cost more than the shorter chains save. So: narrow heads only. The bound is per SAMPLE -- geometry, not S.
-  if ((long long)G * p->m_tiles * p->n_tiles * p->nsl > 8) return false;
+  static const int gate = [] { const char* e = getenv("BT_SKINNY_MAX"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();   // measurement knob
+  if ((long long)G * p->m_tiles * p->n_tiles * p->nsl > gate) return false;
   p->tiles = (long long)G * S * p->m_tiles * p->n_tiles;
   if (p->tiles > kSkinnyMaxTiles || p->tiles * p->nsl > 0x7FFFFFFFll) return false;
   p->scratch = p->tiles * p->nsl * (64ll * kSkinnyCols * 4);

@@ -12,6 +12,7 @@ SHAPES = {  # Ci, Co, k, stride, pad, H
     "r50l3c3": (256, 1024, 1, 1, 0, 14), "r50l3c1": (1024, 256, 1, 1, 0, 14), "r50l1c3": (64, 256, 1, 1, 0, 56), "r50l2ds": (256, 512, 1, 2, 0, 56),
     "r50l3ds": (512, 1024, 1, 2, 0, 28), "r50l4ds": (1024, 2048, 1, 2, 0, 14), "r50l4c1": (2048, 512, 1, 1, 0, 7), "r50l4c3": (512, 2048, 1, 1, 0, 7),
     "r50l2c1": (512, 128, 1, 1, 0, 28), "r50l2c3": (128, 512, 1, 1, 0, 28), "r50l1ds": (64, 256, 1, 1, 0, 56),
+    "lin1024": (1024, 512, 1, 1, 0, 1), "lin2048": (2048, 512, 1, 1, 0, 1), "lin3072": (3072, 512, 1, 1, 0, 1), "lin4096x1024": (4096, 1024, 1, 1, 0, 1),
     "layer3": (256, 256, 3, 1, 1, 2), "layer4": (512, 512, 3, 1, 1, 1), "ds4": (256, 512, 1, 2, 0, 2), "l4s": (256, 512, 3, 2, 1, 2),
 }
 ap = argparse.ArgumentParser()
