@@ -158,7 +158,7 @@ extern "C" int bt_pack_sync(int32_t n_segments, const bt_pack_seg* segs, void* w
   for (int i = 0; i < n_segments; ++i) {
     const bt_pack_seg& s_ = segs[i];
     long long nb = (fp.n[i] + kFpElemsPerBlock - 1) / kFpElemsPerBlock;
-    if (nb > 128) nb = 128;
+    if (nb > 128) nb = 128;   // (more blocks are slower: every wave ends in one 64-bit atomic on the segment's accumulator -- 1024 blocks: 14 -> 25 us for 1.5 M weights)
     fp.first_block[i] = fblocks, fblocks += (int)nb;
     const long long C4 = (s_.Ci + 3) & ~3ll;
     long long pb = s_.Co * ((C4 + kPackCh - 1) / kPackCh);   // (row, 64-channel chunk) work items

@@ -604,6 +604,9 @@ def main(argv=None):
     S_launch = S // reps
     net = build_model(w, dev)
     fused = (not args.no_fuse) and hasattr(net, "layer1")
+    if not args.no_fuse and not hasattr(net, "layer1"):      # an MLP: the ReLU behind a Linear layer goes into its output stage
+        from bayesian_torch_amd.fuse import fold_relu
+        fold_relu(net)
     if fused:
         H.fuse_inference(net)      # BN(eval)/ReLU/residual add folded into the conv kernels' output stage
     torch.manual_seed(0)
