@@ -550,3 +550,28 @@ def test_hip_maxpool_pass_equals_torch(shape):
     assert torch.equal(torch.nan_to_num(got, nan=0.0), torch.nan_to_num(want, nan=0.0))
     xv = x[:, :, 1:, :][:, :, :, 1:] if min(shape[2:]) > 2 else x      # a view whose planes are not 8-byte aligned goes through dev_f32's copy
     assert torch.equal(torch.nan_to_num(F.maxpool_3x3s2(xv), nan=0.0), torch.nan_to_num(torch.nn.functional.max_pool2d(xv, 3, 2, 1), nan=0.0))
+
+
+def test_fold_relu_equals_the_separate_module():
+    """fuse.fold_relu: Sequential(Linear, ReLU, Linear) with the ReLU in the first layer's output stage -- the same draws, the same bits."""
+    import copy
+    from bayesian_torch_amd import rng
+    from bayesian_torch_amd.fuse import fold_relu
+    from bayesian_torch_amd.harness import resnet as H
+    from bayesian_torch_amd.mc import mc_forward
+    from bayesian_torch_amd.models.dnn_to_bnn import dnn_to_bnn
+    rng.set_mode("philox")
+    torch.manual_seed(1)
+    net = H.mlp((192, 128, 10))
+    dnn_to_bnn(net, {"prior_mu": 0.0, "prior_sigma": 1.0, "posterior_mu_init": 0.0, "posterior_rho_init": -3.0, "type": "Reparameterization",
+                     "moped_enable": False, "moped_delta": 0.5})
+    H.fill_bayes_params(net, 2)
+    net = net.cuda().eval()
+    fused = copy.deepcopy(net)
+    assert fold_relu(fused) == 1 and isinstance(fused[1], torch.nn.Identity) and fold_relu(fused) == 0
+    x = torch.randn(40, 192).cuda()
+    rng.manual_seed(3)
+    a, kla = mc_forward(net, x, 3)
+    rng.manual_seed(3)
+    b, klb = mc_forward(fused, x, 3)
+    assert torch.equal(a, b) and torch.equal(kla, klb)
