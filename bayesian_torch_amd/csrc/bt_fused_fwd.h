@@ -67,6 +67,7 @@ struct FwdArgs {
   int ep_relu;
   int ep_pool, ep_Hp, ep_Wp;  // fused 3x3 / stride 2 / pad 1 max-pool of the output stage (fast flavour, whole-image tiles)
   int out_vec4;  // spatial output stored as float4 along the pixel index (TRANS orientation; Ho*Wo % 4 == 0, aligned tensors)
+  int bn32;                 // general split kernel: 32-channel tiles (launch_split_one)
   unsigned long long* dbg;  // diagnostic stamps (bt_debug_set_stamp_buffer); null in normal operation
   // split flavour: ceil(2^32 / d) of the launch-uniform divisors (0: divide), so the tile decode is a few multiplies
   uint32_t inv_m_tiles, inv_S, inv_n_tiles, inv_n_bt, inv_n_ct, inv_rw, inv_wt, inv_kw;

@@ -101,7 +101,7 @@ __device__ __forceinline__ int div_small(int n, int d) { return d == 1 ? n : d =
 // 32 channels x BM/2 pixels each (2 x 2), BM = 256 or 128. s_out meets the second set in the read-out.
 template <int BN, int BM, int NP, int NPW, int XM, bool FLIP = false>
 __global__ __launch_bounds__(256 + 64 * NPW) void fused_split_kernel(const FwdArgs a) {
-  static_assert(BN == 64 && (BM == 512 || BM == 256 || BM == 128), "tile shapes of this flavour");
+  static_assert((BN == 64 && (BM == 512 || BM == 256 || BM == 128)) || (BN == 32 && BM == 128 && !FLIP), "tile shapes of this flavour");
   static_assert(!FLIP || ((BM == 256 || BM == 128) && NP == 3), "Flipout: the 64 x 256 / 64 x 128 tiles, exact split");
   constexpr int kProducers = 64 * NPW, kThreadsAll = 256 + kProducers;
   constexpr int CWM = FLIP ? 2 : 4, CWN = 4 / CWM, WTM = BM / CWM, TN = BN / CWN / 32, TM = WTM / 32;

@@ -22,9 +22,8 @@ int contraction_mode() {
   return m;
 }
 
-template <int BM, int NP, int NPW, int XM>
+template <int BM, int NP, int NPW, int XM, int BN = 64>
 static int launch_split_cfg(FwdArgs& a, hipStream_t stream) {
-  constexpr int BN = 64;
   constexpr int lds = split_lds_bytes<BN, BM, NP>();
   static_assert(lds <= 160 * 1024, "LDS budget of one CU");
   auto kern = fused_split_kernel<BN, BM, NP, NPW, XM>;
@@ -48,6 +47,11 @@ template <int BM, int NPW>
 static int launch_split_xm(FwdArgs& a, int mode, int xm, hipStream_t stream) {
   if (mode == 2) return launch_split_cfg<BM, 2, NPW, 0>(a, stream);   // (the opt-in 3-term form keeps the generic fetch)
   if constexpr (BM == 128) {
+    if (a.bn32) {   // 32-channel tiles of a launch that would leave CUs idle (launch_split_one); same K order, same bits
+      if (xm == 1) return launch_split_cfg<BM, 3, NPW, 1, 32>(a, stream);
+      if (xm == 2) return launch_split_cfg<BM, 3, NPW, 2, 32>(a, stream);
+      return launch_split_cfg<BM, 3, NPW, 0, 32>(a, stream);
+    }
     if (xm == 1) return launch_split_cfg<BM, 3, NPW, 1>(a, stream);
     if (xm == 2) return launch_split_cfg<BM, 3, NPW, 2>(a, stream);
   } else {
@@ -123,6 +127,7 @@ static int launch_quad(FwdArgs& a, int mode, hipStream_t stream) {
 // 1x1 / stride-1 convolutions with K <= 256 and many pixels (the bottleneck ResNets' expanding / reducing layers): the persistent
 // kernel of bt_fused_split_direct.h. Eligibility is geometric (never a matter of S or of the launch split), and its arithmetic is the
 // general kernel's, so a layer's results do not depend on which of the two serves it.
+static std::atomic<int> g_bn32{-2};   // -2: read BT_BN32 once; -1 automatic; 0 / 1 forced (bt_debug_force_bn32)
 static std::atomic<int> g_direct_off{0};
 static int launch_direct(FwdArgs& a, hipStream_t stream) {
   if (g_direct_off.load(std::memory_order_relaxed)) return 1;
@@ -307,7 +312,24 @@ static int launch_split_one(FwdArgs& a, hipStream_t stream) {
   else if (c128 < 1e30) bm = 128;
   if (!bm) return 1;
   a = bm == 512 ? b512 : bm == 256 ? b256 : b128;
-  const long long total = per * a.m_tiles;
+  // A 128-wide launch that offers at most one workgroup per two CUs (a training step's single sample; an MLP's wide first layer at 8
+  // samples) runs in 32-channel tiles instead: twice the workgroups, each drawing half the weights -- the chain of a workgroup of such a
+  // layer IS its weight synthesis. The K order does not depend on the channel tile, so the results are the same bits (and the choice may
+  // depend on S). BT_BN32 = 0 | 1 forces it off / on where eligible (tests, measurement).
+  int bn32_env = g_bn32.load(std::memory_order_relaxed);
+  if (bn32_env == -2) {
+    const char* e = getenv("BT_BN32");
+    bn32_env = e ? (atoi(e) ? 1 : 0) : -1;
+    g_bn32.store(bn32_env, std::memory_order_relaxed);
+  }
+  a.bn32 = 0;
+  if (bm == 128 && mode != 2 && a.Cog > 32) {
+    const long long wgs64 = per * a.m_tiles;
+    a.bn32 = bn32_env >= 0 ? (bn32_env ? 1 : 0) : (2 * wgs64 <= 256 ? 1 : 0);
+  }
+  long long per_t = per;
+  if (a.bn32) a.n_tiles = (a.Cog + 31) / 32, per_t = (long long)a.G * a.n_tiles * a.S;
+  const long long total = per_t * a.m_tiles;
   if (total <= 0 || total > 0x7FFFFFFFll) return 1;
   a.total_blocks = (int)total;
   a.kl_slices = total < 256 ? (int)total : 256;
@@ -355,6 +377,7 @@ int launch_split(FwdArgs& a, hipStream_t stream) {
 
 // Test hook (not part of include/bt_hip.h): 1 keeps 1x1 convolutions off the direct kernel, so a test can compare the two flavours.
 extern "C" void bt_debug_disable_direct(int off) { bt::g_direct_off.store(off ? 1 : 0, std::memory_order_relaxed); }
+extern "C" void bt_debug_force_bn32(int v) { bt::g_bn32.store(v < 0 ? -1 : (v ? 1 : 0), std::memory_order_relaxed); }
 extern "C" void bt_debug_disable_skinny(int off) { bt::g_skinny_off.store(off ? 1 : 0, std::memory_order_relaxed); }
 
 // Contraction arithmetic of the fused forwards (process-wide knob; also env BT_CONTRACTION = f32 | bf16x3 | bf16x2):

@@ -575,3 +575,63 @@ def test_fold_relu_equals_the_separate_module():
     rng.manual_seed(3)
     b, klb = mc_forward(fused, x, 3)
     assert torch.equal(a, b) and torch.equal(kla, klb)
+
+
+@pytest.mark.parametrize("case", ["layer1 64x64 3x3 8x8, one sample (generic fetch)", "Linear 3072 -> 512, b256, S = 2 (xm 1), bias + ReLU", "3x3 on 2x2 maps 256 -> 96 (xm 2, partial tile)",
+                                  "1x1 maps 3x3 512 -> 160, residual + BN + ReLU"])
+def test_32_channel_tiles_are_the_same_bits(case):
+    """Launches that would leave CUs idle run the general split kernel in 32-channel tiles (launch_split_one: bn32). The K order does
+    not depend on the channel tile: the same bits as the 64-channel tiles, KL included; and against the C oracle."""
+    from oracle import c_oracle as CO
+    from bayesian_torch_amd import _lib
+    from bayesian_torch_amd import functional as F
+    g = torch.Generator().manual_seed(abs(hash(case)) % (1 << 31))
+    dev = torch.device("cuda")
+    kw = {}
+    if case.startswith("Linear"):
+        S, B = 2, 256
+        mu, rho = (torch.randn(512, 3072, generator=g) * 0.05).to(dev), (torch.randn(512, 3072, generator=g) * 0.1 - 3).to(dev)
+        x, conv, oshape = torch.randn(S * B, 3072, generator=g).to(dev), None, (512,)
+        mb, rb = (torch.randn(512, generator=g) * 0.1).to(dev), (torch.randn(512, generator=g) * 0.1 - 3).to(dev)
+        kw = dict(relu=True)
+    else:
+        Ci, Co, H, B, S = (64, 64, 8, 16, 1) if case.startswith("layer1") else (256, 96, 2, 48, 2) if case.startswith("3x3 on") else (512, 160, 1, 128, 2)
+        mu, rho = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.1).to(dev), (torch.randn(Co, Ci, 3, 3, generator=g) * 0.1 - 3).to(dev)
+        x, conv, oshape = torch.randn(S * B, Ci, H, H, generator=g).to(dev), dict(stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1), (Co, H, H)
+        mb = rb = None
+        if "residual" in case:
+            kw = dict(post_scale=(torch.rand(Co, generator=g) + 0.5).to(dev), post_shift=(torch.randn(Co, generator=g) * 0.1).to(dev),
+                      residual=torch.randn((S * B,) + oshape, generator=g).to(dev), relu=True)
+    pri = (torch.zeros_like(mu), torch.ones_like(mu), None if mb is None else torch.zeros_like(mb), None if mb is None else torch.ones_like(mb))
+    pk = F.pack_params(mu, rho)
+    L = _lib.lib()
+    L.bt_debug_force_bn32.argtypes = [__import__("ctypes").c_int]
+    L.bt_debug_force_bn32.restype = None
+
+    def run(v):
+        L.bt_debug_force_bn32(v)
+        L.bt_debug_disable_skinny(1)
+        L.bt_debug_disable_direct(1)
+        try:
+            out, kl = F.fused_forward(x, mu, rho, mb, rb, conv=conv, S=S, shared_x=False, seed=4, call=2, layer_id=6, sample0=3, packed=pk, priors=pri, want_kl=True,
+                                      workspace_owner="t_bn32", **kw)
+            return out, kl, L.bt_last_kernel_name().decode()
+        finally:
+            L.bt_debug_force_bn32(-1)
+            L.bt_debug_disable_skinny(0)
+            L.bt_debug_disable_direct(0)
+    o32, k32, n32 = run(1)
+    o64, k64, n64 = run(0)
+    assert "fused_split_kernel<32,128" in n32 and "fused_split_kernel<64," in n64, (n32, n64)
+    assert torch.equal(o32, o64) and torch.equal(k32, k64), f"{case}: max abs {float((o32 - o64).abs().max()):.3e}"
+    eps_w = F.rng_fill_normal(4, 2, 6, 3, 0, S, mu.shape, dev).cpu()
+    eps_b = F.rng_fill_normal(4, 2, 6, 3, 1, S, (mu.shape[0],), dev).cpu() if mb is not None else None
+    for s in range(S):
+        want = CO.reparam_fwd(x[s * B:s * B + 8].cpu(), mu.cpu(), rho.cpu(), eps_w[s], None if mb is None else mb.cpu(), None if rb is None else rb.cpu(),
+                              None if eps_b is None else eps_b[s], conv)
+        if "residual" in case:
+            shp = (1, -1, 1, 1)
+            want = torch.relu(want * kw["post_scale"].cpu().view(shp) + kw["post_shift"].cpu().view(shp) + kw["residual"][s * B:s * B + 8].cpu())
+        elif kw.get("relu"):
+            want = torch.relu(want)
+        assert_close(o32[s * B:s * B + 8].cpu(), want, RTOL, ATOL, f"{case}[s={s}] vs C oracle")
