@@ -113,6 +113,11 @@ class FusedBayesLayer(BaseVariationalLayer_):
     def _prior_kind(self):
         return check_prior_type(getattr(self, "prior_type", "normal"))
 
+    def __getstate__(self):     # (copy.deepcopy / pickle: the cached pack-check entry holds ctypes pointers and belongs to THIS object's tensors)
+        d = self.__dict__.copy()
+        d.pop("_seg_cache", None)
+        return d
+
     def _param_versions(self):
         return tuple(t._version for sg in self._kl_segments() for t in sg[:2])
 
