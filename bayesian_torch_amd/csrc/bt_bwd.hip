@@ -508,7 +508,8 @@ static int conv2d_bwd_impl(const bt_conv2d_geom* g, int32_t S, int32_t flipout, 
   // dgrad's partials live behind wgrad's
   a.part_d = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (size_t)2 * wgrad_groups(*g, S) * g->Co * a.T * a.Cig4 * sizeof(float));
   const long long nwb = (long long)wgrid.x * wgrid.y * wgrid.z, ndb = (long long)dgrid.x * dgrid.y * dgrid.z;
-  if (dx && dmu_w && nwb + ndb < 0x7FFFFFFFll) {   // both passes: ONE launch, and one for the two finishing passes
+  static const bool no_pair = [] { const char* e = getenv("BT_NO_BWD_PAIR"); return e && *e && *e != '0'; }();   // measurement knob: the two passes as launches of their own
+  if (!no_pair && dx && dmu_w && nwb + ndb < 0x7FFFFFFFll) {   // both passes: ONE launch, and one for the two finishing passes
     a.pair_wx = (int)wgrid.x, a.pair_wy = (int)wgrid.y, a.pair_nw = (int)nwb, a.pair_dx = (int)dgrid.x, a.pair_dy = (int)dgrid.y;
     if (flipout) hipLaunchKernelGGL(bwd_pair_kernel<true>, dim3((unsigned)(nwb + ndb)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(bwd_pair_kernel<false>, dim3((unsigned)(nwb + ndb)), dim3(256), 0, st, a);
