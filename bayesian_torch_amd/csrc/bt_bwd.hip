@@ -172,6 +172,15 @@ __device__ __forceinline__ void dgrad_finish_body(const BwdArgs& a, const int bi
 }
 __global__ __launch_bounds__(256) void dgrad_finish_kernel(const BwdArgs a) { dgrad_finish_body(a, blockIdx.x, gridDim.x); }
 
+// n / d (0 <= n < 2^31, d >= 1) through the reciprocal inv = ceil(2^32 / d): the estimate is the quotient or one more, one compare fixes it.
+__device__ __forceinline__ uint32_t recip32(int d) { return d > 1 ? 0xFFFFFFFFu / (uint32_t)d + 1u : 0u; }
+__device__ __forceinline__ int div_recip(int n, int d, uint32_t inv) {
+  if (d == 1) return n;
+  uint32_t q = __umulhi((uint32_t)n, inv);
+  if (q * (uint32_t)d > (uint32_t)n) --q;
+  return (int)q;
+}
+
 // ------------------------------------------------------------------------------------------------------------ wgrad
 // grid: (k' tiles of 64 over T*Cig4) x (co tiles of 64 per group) x (groups * G); group q = (sample group q % sgroups: samples
 // s = q % sgroups + i * sgroups) x (chunk q / sgroups of the reduction axis M = B*Ho*Wo: rows [c * mchunk, (c + 1) * mchunk))
@@ -196,6 +205,7 @@ __device__ __forceinline__ void wgrad_body(const BwdArgs& a, float (*As)[kBK][kL
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc_mu[r] = 0.f, acc_rho[r] = 0.f;
 
+  const uint32_t inv_howo = recip32(HoWo), inv_wo = recip32(a.Wo);
   const int sg0 = sgrp % a.sgroups, mlo = (sgrp / a.sgroups) * a.mchunk, mhi = mlo + a.mchunk < M ? mlo + a.mchunk : M;
   for (int s = sg0; s < a.S; s += a.sgroups) {
     const uint32_t sample = a.sample0 + (uint32_t)s;
@@ -214,7 +224,8 @@ __device__ __forceinline__ void wgrad_body(const BwdArgs& a, float (*As)[kBK][kL
       for (int j = 0; j < 4; ++j) {
         const int mm = (tid >> 6) + 4 * j, m = mm0 + mm;
         const bool mok = m < mhi;
-        const int b = mok ? m / HoWo : 0, p = mok ? m - b * HoWo : 0, ho = p / a.Wo, wo = p - ho * a.Wo;
+        // (reciprocal multiplies: two integer divisions per element and stage were ~a quarter of this loop's instructions)
+        const int b = mok ? div_recip(m, HoWo, inv_howo) : 0, p = mok ? m - b * HoWo : 0, ho = div_recip(p, a.Wo, inv_wo), wo = p - ho * a.Wo;
         float ga = 0.f, gp = 0.f, xv = 0.f, xp = 0.f;
         if (mok && cok) {
           const long long oi = ((long long)b * a.Co + grp * a.Cog + aco) * HoWo + p;
