@@ -251,20 +251,33 @@ __device__ __forceinline__ void wgrad_body(const BwdArgs& a, float (*As)[kBK][kL
     }
     // chain rule of this sample: the mean path adds to dmu, the eps-weighted (perturbation) path to the rho accumulator
     const int kpl = k0 + wc + li, ltap = kpl < KP ? kpl / a.Cig4 : 0, lci = kpl - ltap * a.Cig4;
+    // On-chip draws: the four lanes of a quad (columns 4 q .. 4 q + 3 = the four channels of ONE Philox block of a row) used to run the
+    // same block each, once per accumulator row -- 16 blocks per lane and sample. Now lane j of the quad draws the blocks of the rows
+    // r = j (mod 4) and the quad exchanges them: 4 blocks per lane, the same values.
+    float Z[4][4];
+    if (!a.eps_w) {
+      const bool quad_ok = (kpl & ~3) < KP && (lci & ~3) < a.Cig;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = 4 * t + (li & 3), cog = co0 + wr + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        Z[t][0] = Z[t][1] = Z[t][2] = Z[t][3] = 0.f;
+        if (quad_ok && cog < a.Cog)
+          philox_normal4(kw, sample, (((uint32_t)(grp * a.Cog + cog) * (uint32_t)a.T + (uint32_t)ltap) * (uint32_t)a.Cig4 + (uint32_t)lci) >> 2, Z[t]);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cog = co0 + wr + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const bool ok = kpl < KP && lci < a.Cig && cog < a.Cog;
       float e = 0.f;
-      if (kpl < KP && lci < a.Cig && cog < a.Cog) {
-        const int co = grp * a.Cog + cog;
-        if (a.eps_w) {
-          e = a.eps_w[(long long)s * a.w_elems + ((long long)co * a.Cig + lci) * a.T + ltap];
-        } else {
-          float z[4];
-          philox_normal4(kw, sample, (((uint32_t)co * (uint32_t)a.T + (uint32_t)ltap) * (uint32_t)a.Cig4 + (uint32_t)lci) >> 2, z);
-          const int sel = lci & 3;
-          e = sel == 0 ? z[0] : sel == 1 ? z[1] : sel == 2 ? z[2] : z[3];
-        }
+      if (a.eps_w) {
+        if (ok) e = a.eps_w[(long long)s * a.w_elems + ((long long)(grp * a.Cog + cog) * a.Cig + lci) * a.T + ltap];
+      } else {
+        const int src = (lane & ~3) | (r & 3);   // the quad lane that drew row r's block
+        const float v0 = __shfl(Z[r >> 2][0], src, 64), v1 = __shfl(Z[r >> 2][1], src, 64), v2 = __shfl(Z[r >> 2][2], src, 64), v3 = __shfl(Z[r >> 2][3], src, 64);
+        const int sel = lci & 3;
+        e = sel == 0 ? v0 : sel == 1 ? v1 : sel == 2 ? v2 : v3;
+        if (!ok) e = 0.f;
       }
       acc_mu[r] = __fadd_rn(acc_mu[r], d[0][r]);
       acc_rho[r] = __fadd_rn(acc_rho[r], __fmul_rn(e, d[FLIP ? 1 : 0][r]));
